@@ -1,0 +1,164 @@
+"""CPU: the oracle (oracle/) is pinned to the golden vectors generated from the reference
+(tests/golden/make_golden.py).  VQ indices bit-exact; floating-point tensors to tight tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as O
+import portable_rng
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_vq_robust_and_ties(golden_dir):
+    g = load(golden_dir, "vq_ops.npz")
+    assert np.array_equal(O.vq_indices(g["f1.x"], g["f1.e"]), g["f1.idx"])
+    codes, idx = O.vq_st(torch.from_numpy(g["f1.x"]), torch.from_numpy(g["f1.e"]))
+    assert np.array_equal(codes.numpy(), g["f1.codes"]) and np.array_equal(idx.numpy(), g["f1.idx"])
+    xb = g["f1b.x"]
+    idx = O.vq(torch.from_numpy(xb), torch.from_numpy(g["f1b.e"]))
+    assert idx.shape == xb.shape[:-1] and idx.dtype == torch.int64
+    assert np.array_equal(idx.numpy(), g["f1b.idx"])
+    assert not np.isin(g["f1b.idx"], [13, 20, 7]).any()  # duplicates never win: first index on ties
+    assert np.array_equal(O.vq_indices(g["f1c.x"], g["f1c.e"]), g["f1c.idx"]) and (g["f1c.idx"] == 0).all()
+
+
+@pytest.mark.parametrize("tag", ["f2a", "f2b", "f2c", "f2d"])
+def test_vq_fragile_bit_exact(golden_dir, tag):
+    g = load(golden_dir, "vq_ops.npz")
+    N, D, K, seed = (int(v) for v in g[tag + ".shape"])
+    x, e = portable_rng.vq_case(N, D, K, seed)
+    chk = np.array([x.astype(np.float64).sum(), e.astype(np.float64).sum()])
+    assert np.array_equal(chk, g[tag + ".xsum"]), "portable RNG no longer reproduces the fixture inputs"
+    assert np.array_equal(O.rowsumsq(x), g[tag + ".x2"])
+    assert np.array_equal(O.rowsumsq(e), g[tag + ".c2"])
+    idx, dmin = O.vq_indices(x, e, return_dist=True)
+    assert np.array_equal(idx, g[tag + ".idx"])
+    assert np.array_equal(dmin, g[tag + ".dmin"])
+
+
+def test_vq_st_backward(golden_dir):
+    g = load(golden_dir, "vq_ops.npz")
+    x = torch.from_numpy(g["st.x"]).requires_grad_(True)
+    e = torch.from_numpy(g["st.e"]).requires_grad_(True)
+    codes, idx = O.vq_st(x, e)
+    (codes * torch.from_numpy(g["st.w"])).sum().backward()
+    assert np.array_equal(idx.numpy(), g["st.idx"])
+    assert np.array_equal(x.grad.numpy(), g["st.gx"])
+    np.testing.assert_allclose(e.grad.numpy(), g["st.ge"], rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        xi = torch.from_numpy(g["st.x"]).requires_grad_(True)
+        O.vq(xi, e).float().sum().backward()
+
+
+def test_resblock(golden_dir):
+    g = load(golden_dir, "resblock.npz")
+    st = {"decoder.9." + k[3:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd.")}
+    x = torch.from_numpy(g["x"])
+    new = {}
+    y = O._resblock(x, st, "decoder.9", True, new)
+    np.testing.assert_allclose(y.numpy(), g["y_train"], rtol=1e-5, atol=1e-6)
+    # the reference mutates its input to relu(x) (nn.ReLU(True), models.py:149)
+    np.testing.assert_array_equal(torch.relu(x).numpy(), g["x_after_train"])
+    for k, v in new.items():
+        np.testing.assert_allclose(v.numpy(), g["sd_after." + k[len("decoder.9."):]], rtol=1e-5, atol=1e-6)
+    # the eval pass of the fixture ran after the train pass, i.e. on the updated running stats
+    st_after = {"decoder.9." + k[len("sd_after."):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd_after.")}
+    ye = O._resblock(x, st_after, "decoder.9", False, {})
+    np.testing.assert_allclose(ye.numpy(), g["y_eval"], rtol=1e-5, atol=1e-6)
+
+
+def _state0(g):
+    return O.state_from_npz(g, "sd0.")
+
+
+def test_state_keys(golden_dir):
+    for name in ("model_tiny.npz", "model_cfg1.npz"):
+        g = load(golden_dir, name)
+        dim, z_dim = (int(v) for v in g["cfg"])
+        st = _state0(g)
+        assert [(k, tuple(v.shape)) for k, v in st.items()] == O.state_keys(dim, z_dim)
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_tiny_model_step(golden_dir, si):
+    g = load(golden_dir, "model_tiny.npz")
+    st = _state0(g)
+    opt = O.adam_init(st)
+    tag = "s%d." % si
+    c = torch.from_numpy(g[tag + "c"])
+    rec = O.train_step(st, opt, c)
+    np.testing.assert_allclose([rec["loss_recons"].item(), rec["loss_vq"].item(), rec["loss_commit"].item()],
+                               g[tag + "losses"], rtol=1e-6)
+    assert np.array_equal(rec["idx"].view(g[tag + "idx"].shape).numpy(), g[tag + "idx"])
+    for k in ("x_tilde", "z_e", "z_q"):
+        np.testing.assert_allclose(rec[k].numpy(), g[tag + k], rtol=1e-5, atol=1e-6)
+    for k, v in rec["grads"].items():
+        np.testing.assert_allclose(v.numpy(), g[tag + "grad." + k], rtol=1e-4, atol=1e-7, err_msg=k)
+    for k, v in st.items():
+        ref = g[tag + "sd1." + k]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref)
+        elif O.is_param(k):
+            # Adam turns round-off-sized gradients (conv biases in front of a BatchNorm) into +-lr
+            # steps, so compare the update only where the gradient is well above round-off.
+            gk = np.abs(g[tag + "grad." + k])
+            big = gk > 1e-6
+            np.testing.assert_allclose(v.numpy()[big], ref[big], rtol=0, atol=2e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(v.numpy(), ref, rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_tiny_eval_encode_decode(golden_dir):
+    g = load(golden_dir, "model_tiny.npz")
+    st = _state0(g)
+    c = torch.from_numpy(g["s0.c"])
+    with torch.no_grad():
+        x_tilde, z_e, z_q, idx, _ = O.forward(st, c, training=False)
+        lat = O.encode(st, c)
+        dec = O.decode(st, lat)
+    np.testing.assert_allclose(x_tilde.numpy(), g["eval.x_tilde"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(lat.numpy(), g["eval.latents"])
+    np.testing.assert_allclose(dec.numpy(), g["eval.decode"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(torch.nn.functional.mse_loss(z_q, z_e).item(), g["eval.loss_vq"], rtol=1e-6)
+
+
+def test_tiny_trajectory(golden_dir):
+    g = load(golden_dir, "model_tiny.npz")
+    st = _state0(g)
+    opt = O.adam_init(st)
+    c = torch.from_numpy(g["s0.c"])
+    traj = []
+    for _ in range(g["traj.losses"].shape[0]):
+        r = O.train_step(st, opt, c)
+        traj.append([r["loss_recons"].item(), r["loss_vq"].item(), r["loss_commit"].item()])
+    np.testing.assert_allclose(np.array(traj), g["traj.losses"], rtol=2e-4)
+
+
+def test_tiny_dp(golden_dir):
+    g = load(golden_dir, "model_tiny.npz")
+    st = _state0(g)
+    opt = O.adam_init(st)
+    recs, avg = O.dp_train_step(st, opt, [torch.from_numpy(g["dp.c0"]), torch.from_numpy(g["dp.c1"])])
+    for k, v in avg.items():
+        np.testing.assert_allclose(v.numpy(), g["dp.grad." + k], rtol=1e-4, atol=1e-7, err_msg=k)
+    got = np.array([[r["loss_recons"].item(), r["loss_vq"].item(), r["loss_commit"].item()] for r in recs])
+    np.testing.assert_allclose(got, g["dp.losses"], rtol=1e-6)
+
+
+def test_cfg1_model_step(golden_dir):
+    g = load(golden_dir, "model_cfg1.npz")
+    st = _state0(g)
+    rec = O.forward_backward(st, torch.from_numpy(g["s0.c"]))
+    np.testing.assert_allclose([rec["loss_recons"].item(), rec["loss_vq"].item(), rec["loss_commit"].item()],
+                               g["s0.losses"], rtol=1e-6)
+    assert np.array_equal(rec["idx"].view(g["s0.idx"].shape).numpy(), g["s0.idx"])
+    for k, v in rec["grads"].items():
+        ref = float(g["s0.gnorm." + k])
+        assert abs(v.double().norm().item() - ref) <= 1e-4 * ref + 1e-7, k
