@@ -1,0 +1,224 @@
+/*
+ * nsg.h -- C ABI of libnsg.so: hand-written gfx950 (MI355X / CDNA4) kernels for the VQ-VAE
+ * training hot path of dendisuhubdy/neural_sound_generation.
+ *
+ * The reference has no native code on this path: it reaches its arithmetic through PyTorch ATen
+ * operators.  Each entry point below therefore replaces one ATen call site of the reference
+ * (file:line given per function, relative to the reference repository root).  The reference-side
+ * binding a maintainer would add (ctypes, from src/models.py / src/vector_quantization.py) is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (including
+ *     workspaces); the library allocates nothing, frees nothing, keeps no pointer after return;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only ENQUEUE work,
+ *     they never synchronise;
+ *   - return value: 0 = OK, <0 = invalid argument / unsupported shape (NSG_E_*), >0 = hipError_t;
+ *     a message for the calling thread's last failure is available from nsg_last_error_string();
+ *   - activations are fp32 NHWC ("channels last"): a tensor the reference holds as (B,C,H,W) is
+ *     stored here as [B][H][W][C].  For C == 1 (the mel input and the reconstruction) the two
+ *     layouts coincide.  Convolution weights are passed in the reference's own layouts
+ *     (Conv2d: [C_out][C_in][kH][kW], ConvTranspose2d: [C_in][C_out][kH][kW]) and re-packed on the
+ *     device by nsg_pack_conv_weights();
+ *   - element counts of any single tensor must stay below 2^31.
+ */
+#ifndef NSG_H_
+#define NSG_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define NSG_API __attribute__((visibility("default")))
+#else
+#define NSG_API
+#endif
+
+#define NSG_VERSION 100 /* 0.1.0 */
+
+enum {
+    NSG_OK = 0,
+    NSG_E_INVALID = -1,     /* null pointer / non-positive size / misaligned pointer */
+    NSG_E_UNSUPPORTED = -2, /* shape outside what the kernels implement (see each function) */
+    NSG_E_WORKSPACE = -3    /* workspace too small */
+};
+
+/* flags shared by the convolution entry points */
+enum {
+    NSG_RELU_IN = 1,   /* apply max(0,.) to the (gathered) input operand while loading it          */
+    NSG_TANH_OUT = 2,  /* apply tanh to the result (forward only)                                   */
+    NSG_RELU_IN2 = 4   /* wgrad only: apply max(0,.) to the output-side operand (see nsg_conv_wgrad) */
+};
+
+/* Geometry of one convolution layer.  transposed = 0: nn.Conv2d(C_in, C_out, k, stride, pad);
+ * transposed = 1: nn.ConvTranspose2d(C_in, C_out, k, stride, pad).  (IH,IW) is the layer's input
+ * extent, (OH,OW) its output extent; both are given so the library never has to guess.
+ * Supported: Conv2d with any k <= 7, stride in {1,2}; ConvTranspose2d with k=4, stride=2, pad=1
+ * (the only transposed geometry on the path: src/models.py:179,182).  C_in and C_out must be
+ * multiples of 4 or equal to 1. */
+typedef struct nsg_conv_desc {
+    int32_t B, IH, IW, C_in;
+    int32_t OH, OW, C_out;
+    int32_t k, stride, pad;
+    int32_t transposed;
+} nsg_conv_desc;
+
+NSG_API int nsg_version(void);
+NSG_API const char *nsg_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vector quantiser                                        src/vector_quantization.py
+ * ------------------------------------------------------------------------------------------- */
+
+/* Bytes of workspace nsg_vq_forward needs for N rows and K codes. */
+NSG_API size_t nsg_vq_workspace_bytes(int64_t N, int32_t D, int32_t K);
+
+/* Fused nearest-code search.  Replaces VectorQuantization.forward (vector_quantization.py:6-23:
+ * torch.sum(x**2), torch.sum(e**2), torch.addmm(..., alpha=-2, beta=1), torch.min(dim=1)) and the
+ * gather of VectorQuantizationStraightThrough.forward (:40-42, torch.index_select), without ever
+ * materialising the (N,K) distance matrix.
+ *   x [N][D] fp32 rows, e [K][D] fp32 codebook, idx_out [N] int64 (first minimal index on ties,
+ *   bit-exact with the reference's CPU result -- see DESIGN.md "bit-exact argmin"),
+ *   codes_out [N][D] = e[idx] or NULL, dmin_out [N] fp32 minimal distance or NULL.
+ * Supported: 1 <= D <= 256, K >= 1. */
+NSG_API int nsg_vq_forward(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+                           float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[r] = torch.sum(v[r]**2) with ATen's CPU summation order (vector_quantization.py:12-13). */
+NSG_API int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream);
+
+/* Bytes of workspace for nsg_index_add_rows. */
+NSG_API size_t nsg_index_add_workspace_bytes(int64_t N, int32_t D, int32_t K);
+
+/* out[k][:] = sum over rows i with idx[i] == k of g[i][:]  (out fully overwritten).
+ * Replaces grad_codebook.index_add_(0, indices, grad_output) (vector_quantization.py:60-61) and the
+ * autograd of torch.index_select(self.embedding.weight, 0, indices) (src/models.py:137-138); also
+ * yields the per-code sums of the EMA codebook extension.  Deterministic (fixed summation order).
+ * counts_out [K] fp32 (rows per code) or NULL. */
+NSG_API int nsg_index_add_rows(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
+                               float *counts_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[i][:] = e[idx[i]][:] for i < N.  Replaces torch.index_select(codebook, 0, indices)
+ * (vector_quantization.py:40-41, src/models.py:137) and self.codebook.embedding(latents)
+ * (src/models.py:194).  Indices outside [0,K) are clamped. */
+NSG_API int nsg_gather_rows(const float *e, const int64_t *idx, int64_t N, int32_t D, int32_t K, float *out,
+                            void *stream);
+
+/* EMA codebook update (extension, not in the reference; VQ-VAE paper appendix A.1):
+ *   ema_n = decay*ema_n + (1-decay)*n;  ema_s = decay*ema_s + (1-decay)*s;
+ *   e[k] = ema_s[k] / ((ema_n[k]+eps) / (sum(ema_n) + K*eps) * sum(ema_n)).
+ * n [K], s [K][D] are the (all-reduced) batch statistics from nsg_index_add_rows.
+ * scratch: one device float (holds sum(ema_n) between the two kernels). */
+NSG_API int nsg_vq_ema_update(float *e, float *ema_n, float *ema_s, const float *n, const float *s, int32_t K,
+                              int32_t D, float decay, float eps, float *scratch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolutions                                            src/models.py:150,153,165,168,179,182
+ * ------------------------------------------------------------------------------------------- */
+
+/* Floats in each packed weight image (forward image, dgrad image). */
+NSG_API size_t nsg_packed_weight_floats(const nsg_conv_desc *d);
+
+/* Re-pack reference-layout weights into the two [tap][n][c] images the GEMM kernels stream:
+ * w_fwd for nsg_conv_forward, w_dgrad for nsg_conv_dgrad (either may be NULL to skip it). */
+NSG_API int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, float *w_fwd, float *w_dgrad, void *stream);
+
+/* Workspace bytes for forward/dgrad (C == 1 layers stage im2col/col2im images) and wgrad (split-K slabs). */
+NSG_API size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d);
+
+/* y = conv(x) + bias.  Replaces F.conv2d / F.conv_transpose2d as called by nn.Conv2d /
+ * nn.ConvTranspose2d.forward at src/models.py:150,153,165,168,179,182.
+ * flags: NSG_RELU_IN (the preceding nn.ReLU fused into the load), NSG_TANH_OUT (models.py:183). */
+NSG_API int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y,
+                             int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/* dx = d loss / d x given dy (autograd of the calls above).  flags: none. */
+NSG_API int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad, float *dx, int32_t flags,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* dw (reference weight layout, fully overwritten) and dbias (or NULL) given x and dy.
+ * flags: NSG_RELU_IN treats x as max(0,x) (the fused preceding ReLU).  Deterministic. */
+NSG_API int nsg_conv_wgrad(const nsg_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
+                           int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d over [M][C] (M = B*H*W)                     src/models.py:151,154,166,180
+ * ------------------------------------------------------------------------------------------- */
+
+NSG_API size_t nsg_bn_workspace_bytes(int64_t M, int32_t C);
+
+/* Training-mode statistics: mean[C], invstd[C] = 1/sqrt(biased var + eps); if running_mean/var are
+ * non-NULL they are updated with `momentum` (running_var takes the unbiased variance), as
+ * F.batch_norm(training=True) does. */
+NSG_API int nsg_bn_stats(const float *x, int64_t M, int32_t C, float eps, float momentum, float *mean, float *invstd,
+                         float *running_mean, float *running_var, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* Eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps). */
+NSG_API int nsg_bn_eval_stats(const float *running_mean, const float *running_var, int32_t C, float eps, float *mean,
+                              float *invstd, void *stream);
+
+/* y = (x-mean)*invstd*gamma + beta; relu != 0: y = max(0,y); residual != NULL: y += residual
+ * (relu_residual != 0: y += max(0,residual) -- the ResBlock's in-place-ReLU'd skip, models.py:149,158). */
+NSG_API int nsg_bn_apply(const float *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                         const float *residual, float *y, int64_t M, int32_t C, int32_t relu, int32_t relu_residual,
+                         void *stream);
+
+/* Backward of the call above with respect to x, gamma, beta.  y_relu: the forward OUTPUT when
+ * relu != 0 was used (its sign is the ReLU mask), else NULL.  dgamma/dbeta [C] overwritten. */
+NSG_API int nsg_bn_backward(const float *x, const float *y_relu, const float *dy, const float *mean,
+                            const float *invstd, const float *gamma, float *dx, float *dgamma, float *dbeta, int64_t M,
+                            int32_t C, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Element-wise, losses, optimiser                         src/train.py:118-136
+ * ------------------------------------------------------------------------------------------- */
+
+/* dx = (a + b) * (x > 0)   (b may be NULL): gradient through the ResBlock's leading in-place ReLU. */
+NSG_API int nsg_relu_backward_add(const float *a, const float *b, const float *x, float *dx, int64_t n, void *stream);
+
+/* dx = g * (1 - y*y): backward of nn.Tanh (models.py:183) from its output y. */
+NSG_API int nsg_tanh_backward(const float *g, const float *y, float *dx, int64_t n, void *stream);
+
+/* y = a + b (b may be NULL -> copy). */
+NSG_API int nsg_add(const float *a, const float *b, float *y, int64_t n, void *stream);
+
+NSG_API size_t nsg_reduce_workspace_bytes(int64_t n);
+
+/* loss_out[0] = mean over rows*wc elements of (pad(a) - c)^2 where a is [rows][wa], c is [rows][wc],
+ * wa <= wc and a is zero-padded on the right to wc: the reference's zero-pad + F.mse_loss
+ * (src/train.py:118-129).  da (or NULL) receives grad_scale * 2/(rows*wc) * (a - c[:, :wa]). */
+NSG_API int nsg_mse_padded(const float *a, const float *c, int64_t rows, int32_t wa, int32_t wc, float grad_scale,
+                           float *loss_out, float *da, void *workspace, size_t workspace_bytes, void *stream);
+
+/* loss_out[0] = mean((q - z)^2) over n elements (train.py:131,133: both terms have this value);
+ * dz (or NULL) = dz_scale * 2/n * (z - q) (+ dz_add if non-NULL: the straight-through gradient),
+ * dq (or NULL) = dq_scale * 2/n * (q - z). */
+NSG_API int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_scale, float dq_scale,
+                          const float *dz_add, float *loss_out, float *dz, float *dq, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* torch.optim.Adam step (src/main.py:124 defaults, no weight decay, no amsgrad) over one flat
+ * fp32 buffer.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
+ * step is the 1-based step count. */
+NSG_API int nsg_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, int32_t step, float grad_scale, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Self-checks used by the tests
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[i*K+k] = x[i]·e[k] evaluated (mode 0) as a sequential fmaf chain on the vector ALU and
+ * (mode 1) on v_mfma_f32_32x32x2_f32 in the order nsg_vq_forward uses; the two must agree bit for
+ * bit for the argmin to be exact.  N, K multiples of 32, D <= 256. */
+NSG_API int nsg_debug_dot(const float *x, const float *e, int32_t N, int32_t D, int32_t K, int32_t mode, float *out,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSG_H_ */

@@ -1,0 +1,103 @@
+"""ctypes binding of libnsg.so (the C ABI declared in include/nsg.h).
+
+There is no fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+The oracle under oracle/ is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnsg.so")
+
+NSG_RELU_IN = 1
+NSG_TANH_OUT = 2
+
+
+class ConvDesc(Structure):
+    """struct nsg_conv_desc (include/nsg.h)."""
+    _fields_ = [("B", c_int32), ("IH", c_int32), ("IW", c_int32), ("C_in", c_int32),
+                ("OH", c_int32), ("OW", c_int32), ("C_out", c_int32),
+                ("k", c_int32), ("stride", c_int32), ("pad", c_int32), ("transposed", c_int32)]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+_P = c_void_p
+_D = POINTER(ConvDesc)
+# name -> (restype, argtypes); restype None means "int status, checked"
+_SIGS = {
+    "nsg_version": (c_int32, []),
+    "nsg_last_error_string": (c_char_p, []),
+    "nsg_vq_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "nsg_vq_forward": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+    "nsg_debug_vq_forward_valu": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+    "nsg_rowsumsq": (None, [_P, c_int64, c_int32, _P, _P]),
+    "nsg_index_add_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "nsg_index_add_rows": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "nsg_gather_rows": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P]),
+    "nsg_vq_ema_update": (None, [_P, _P, _P, _P, _P, c_int32, c_int32, c_float, c_float, _P, _P]),
+    "nsg_packed_weight_floats": (c_size_t, [_D]),
+    "nsg_pack_conv_weights": (None, [_D, _P, _P, _P, _P]),
+    "nsg_conv_workspace_bytes": (c_size_t, [_D]),
+    "nsg_conv_forward": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_conv_dgrad": (None, [_D, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_conv_wgrad": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "nsg_bn_stats": (None, [_P, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "nsg_bn_eval_stats": (None, [_P, _P, c_int32, c_float, _P, _P, _P]),
+    "nsg_bn_apply": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
+    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, _P]),
+    "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),
+    "nsg_add": (None, [_P, _P, _P, c_int64, _P]),
+    "nsg_reduce_workspace_bytes": (c_size_t, [c_int64]),
+    "nsg_mse_padded": (None, [_P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, c_size_t, _P]),
+    "nsg_vq_losses": (None, [_P, _P, c_int64, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "nsg_adam_step": (None, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, _P]),
+    "nsg_debug_dot": (None, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+}
+# entry points declared in include/nsg.h (nsg_debug_vq_forward_valu is a test hook outside the header)
+HEADER_SYMBOLS = [k for k in _SIGS if k != "nsg_debug_vq_forward_valu"]
+
+_lib = None
+
+
+class NsgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnsg.so; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NsgError(
+            f"{LIB_PATH} is missing: build the HIP kernels first (python -m neural_sound_generation_amd.build). "
+            "There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int32 if res is None else res
+    if lib.nsg_version() < 100:
+        raise NsgError("libnsg.so is older than this package")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point; raise with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.nsg_last_error_string()
+        raise NsgError(f"{name} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def query(name: str, *args):
+    return getattr(load(), name)(*args)

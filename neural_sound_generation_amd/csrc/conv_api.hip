@@ -1,0 +1,382 @@
+// Convolution entry points: geometry checks, weight re-packing, the single-channel (C == 1)
+// im2col / col2im stagings, bias gradients, and dispatch onto the two GEMM kernels.
+// Reference call sites: src/models.py:150,153,165,168 (nn.Conv2d), :179,182 (nn.ConvTranspose2d).
+#include "nsg_common.h"
+
+namespace {
+
+// dst[(t*NN + n)*CC + c] = src[n*sn + c*sc + (flip ? T-1-t : t)]
+__global__ void pack_w_kernel(const float *__restrict__ src, float *__restrict__ dst, int T, int NN, int CC, int sn, int sc, int flip)
+{
+    const int64_t total = (int64_t)T * NN * CC;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CC);
+        const int n = (int)((i / CC) % NN);
+        const int t = (int)(i / ((int64_t)CC * NN));
+        dst[i] = src[(size_t)n * sn + (size_t)c * sc + (flip ? T - 1 - t : t)];
+    }
+}
+
+// img [B][HH][WW] (one channel) -> patches [B][LH][LW][16], tap = kh*4+kw, pixel (2ly+kh-1, 2lx+kw-1)
+// (LH,LW) = floor(HH/2), floor(WW/2): the 4/2/1 convolution's output grid
+__global__ void im2col_c1_kernel(const float *__restrict__ img, float *__restrict__ patches, int B, int LH, int LW, int HH, int WW)
+{
+    const int64_t total = (int64_t)B * LH * LW * 4;  // one thread per (pixel, kh)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kh = (int)(i & 3);
+        const int64_t pix = i >> 2;
+        const int lx = (int)(pix % LW);
+        const int ly = (int)((pix / LW) % LH);
+        const int b = (int)(pix / ((int64_t)LW * LH));
+        const int y = 2 * ly + kh - 1;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < HH) {
+            const float *row = img + ((size_t)b * HH + y) * WW;
+            const int x0 = 2 * lx - 1;
+            if (x0 >= 0) v.x = row[x0];
+            v.y = row[x0 + 1];
+            if (x0 + 2 < WW) v.z = row[x0 + 2];
+            if (x0 + 3 < WW) v.w = row[x0 + 3];
+        }
+        *reinterpret_cast<v4f *>(patches + i * 4) = v;
+    }
+}
+
+// dots [B][LH][LW][16] -> out [B][HH][WW]:  out[y][x] = bias + sum of the (<= 4) taps that reach it
+__global__ void col2im_c1_kernel(const float *__restrict__ dots, const float *__restrict__ bias, float *__restrict__ out, int B,
+                                 int LH, int LW, int HH, int WW, int tanh_out)
+{
+    const int64_t total = (int64_t)B * HH * WW;
+    const float bv = bias ? bias[0] : 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % WW);
+        const int y = (int)((i / WW) % HH);
+        const int b = (int)(i / ((int64_t)WW * HH));
+        const int py = y & 1, px = x & 1, ry = y >> 1, rx = x >> 1;
+        float acc = bv;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ly = ry + py - a;
+            const int kh = (1 - py) + 2 * a;
+            if (ly < 0 || ly >= LH) continue;
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int lx = rx + px - b2;
+                const int kw = (1 - px) + 2 * b2;
+                if (lx < 0 || lx >= LW) continue;
+                acc += dots[(((size_t)b * LH + ly) * LW + lx) * 16 + kh * 4 + kw];
+            }
+        }
+        out[i] = tanh_out ? tanhf(acc) : acc;
+    }
+}
+
+// column sums of [M][C] in two deterministic stages
+constexpr int CS_MAX_SLABS = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, int64_t M, int C, int slab_rows,
+                                                             float *__restrict__ partial)
+{
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int Cb = C < 256 ? C : 256;
+    const int rgroups = 256 / Cb;
+    const int cl = tid % Cb, rg = tid / Cb;
+    const int64_t r0 = (int64_t)blockIdx.x * slab_rows;
+    const int64_t r1 = min(M, r0 + slab_rows);
+    for (int cb = 0; cb < C; cb += Cb) {
+        const int c = cb + cl;
+        float s = 0.f;
+        if (rg < rgroups && c < C)
+            for (int64_t r = r0 + rg; r < r1; r += rgroups) s += x[r * C + c];
+        red[tid] = (rg < rgroups) ? s : 0.f;
+        __syncthreads();
+        if (tid < Cb && cb + tid < C) {
+            float t = 0.f;
+            for (int g = 0; g < rgroups; ++g) t += red[g * Cb + tid];
+            partial[(size_t)blockIdx.x * C + cb + tid] = t;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_kernel(const float *__restrict__ partial, int nslab, int C, float *out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < nslab; ++i) s += (double)partial[(size_t)i * C + c];
+    out[c] = (float)s;
+}
+
+struct CsGeom { int nslab, rows; };
+inline CsGeom cs_geom(int64_t M)
+{
+    CsGeom g;
+    int64_t n = nsg_cdiv(M, 512);
+    if (n > CS_MAX_SLABS) n = CS_MAX_SLABS;
+    if (n < 1) n = 1;
+    g.rows = (int)nsg_cdiv(M, n);
+    g.nslab = (int)nsg_cdiv(M, g.rows);
+    return g;
+}
+inline size_t colsum_ws_bytes(int64_t M, int C) { return nsg_align_up((size_t)cs_geom(M).nslab * C * sizeof(float), 256); }
+
+int colsum(const float *x, int64_t M, int C, float *out, void *ws, hipStream_t s)
+{
+    const CsGeom g = cs_geom(M);
+    float *partial = reinterpret_cast<float *>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, g.nslab, C, out);
+    return nsg_check_launch("colsum");
+}
+
+inline int ew_blocks(int64_t n)
+{
+    int64_t b = nsg_cdiv(n, 256);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+enum Kind { K_CONV, K_CONVT, K_CONV_C1, K_CONVT_C1 };
+
+// validates the descriptor; returns <0 on error, else the layer kind
+int classify(const nsg_conv_desc *d, const char *fn)
+{
+    if (!d) return nsg_fail(NSG_E_INVALID, "%s: null descriptor", fn);
+    if (d->B <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->C_in <= 0 || d->C_out <= 0 || d->k <= 0)
+        return nsg_fail(NSG_E_INVALID, "%s: non-positive geometry", fn);
+    const int64_t nin = (int64_t)d->B * d->IH * d->IW * d->C_in, nout = (int64_t)d->B * d->OH * d->OW * d->C_out;
+    if (nin >= (1ll << 31) || nout >= (1ll << 31)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: tensor with >= 2^31 elements", fn);
+    if (!d->transposed) {
+        if (d->k > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0 || d->pad >= d->k)
+            return nsg_fail(NSG_E_UNSUPPORTED, "%s: Conv2d k=%d stride=%d pad=%d not supported", fn, d->k, d->stride, d->pad);
+        if (d->OH != (d->IH + 2 * d->pad - d->k) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - d->k) / d->stride + 1)
+            return nsg_fail(NSG_E_INVALID, "%s: output extent does not match Conv2d geometry", fn);
+        if (d->C_in == 1) {
+            if (!(d->k == 4 && d->stride == 2 && d->pad == 1 && d->C_out % 4 == 0))
+                return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in=1 needs k=4,stride=2,pad=1 and C_out%%4==0", fn);
+            return K_CONV_C1;
+        }
+        if (d->C_in % 4 || d->C_out % 4) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of 4", fn);
+        if (d->stride == 2 && !(d->k == 4 && d->pad == 1))
+            return nsg_fail(NSG_E_UNSUPPORTED, "%s: stride-2 Conv2d needs k=4,pad=1", fn);
+        return K_CONV;
+    }
+    if (!(d->k == 4 && d->stride == 2 && d->pad == 1)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: ConvTranspose2d needs k=4,stride=2,pad=1", fn);
+    if (d->OH != 2 * d->IH || d->OW != 2 * d->IW) return nsg_fail(NSG_E_INVALID, "%s: output extent does not match ConvTranspose2d geometry", fn);
+    if (d->C_out == 1) {
+        if (d->C_in % 4) return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in must be a multiple of 4", fn);
+        return K_CONVT_C1;
+    }
+    if (d->C_in % 4 || d->C_out % 4) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of 4", fn);
+    return K_CONVT;
+}
+
+inline int64_t lowres_pixels(const nsg_conv_desc *d)
+{
+    return d->transposed ? (int64_t)d->B * d->IH * d->IW : (int64_t)d->B * d->OH * d->OW;
+}
+inline size_t patches_bytes(const nsg_conv_desc *d) { return nsg_align_up((size_t)lowres_pixels(d) * 16 * sizeof(float), 256); }
+
+GatherGemmParams gg_1x1(const float *in, const float *w, const float *bias, float *out, int64_t M, int CI, int CO, int flags)
+{
+    GatherGemmParams p = {};
+    p.in = in; p.w = w; p.bias = bias; p.out = out;
+    p.B = 1; p.IH = 1; p.IW = (int)M; p.CI = CI;
+    p.OH = 1; p.OW = (int)M; p.CO = CO;
+    p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.mode = 0; p.M = (int)M; p.RH = 1; p.RW = (int)M;
+    p.flags = flags;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nsg_packed_weight_floats(const nsg_conv_desc *d)
+{
+    if (!d) return 0;
+    return (size_t)d->k * d->k * d->C_in * d->C_out;
+}
+
+int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, float *w_fwd, float *w_dgrad, void *stream)
+{
+    const int kind = classify(d, "nsg_pack_conv_weights");
+    if (kind < 0) return kind;
+    NSG_REQUIRE(w, NSG_E_INVALID, "nsg_pack_conv_weights: null weights");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = d->k * d->k, CI = d->C_in, CO = d->C_out;
+    const int nb = ew_blocks((int64_t)T * CI * CO);
+    auto pack = [&](float *dst, int TT, int NN, int CC, int sn, int sc, int flip) {
+        hipLaunchKernelGGL(pack_w_kernel, dim3(nb), dim3(256), 0, s, w, dst, TT, NN, CC, sn, sc, flip);
+    };
+    switch (kind) {
+    case K_CONV:  // w[co][ci][t]
+        if (w_fwd) pack(w_fwd, T, CO, CI, CI * T, T, 0);
+        if (w_dgrad) pack(w_dgrad, T, CI, CO, T, CI * T, d->stride == 1 ? 1 : 0);
+        break;
+    case K_CONVT:  // w[ci][co][t]
+        if (w_fwd) pack(w_fwd, T, CO, CI, T, CO * T, 0);
+        if (w_dgrad) pack(w_dgrad, T, CI, CO, CO * T, T, 0);
+        break;
+    case K_CONV_C1:  // w[co][t] : forward is a 1x1 GEMM over the 16 patch taps
+        if (w_fwd) pack(w_fwd, 1, CO, 16, 16, 1, 0);    // [n=co][c=t]
+        if (w_dgrad) pack(w_dgrad, 1, 16, CO, 1, 16, 0);  // [n=t][c=co]
+        break;
+    case K_CONVT_C1:  // w[ci][t]
+        if (w_fwd) pack(w_fwd, 1, 16, CI, 1, 16, 0);     // [n=t][c=ci]
+        if (w_dgrad) pack(w_dgrad, 1, CI, 16, 16, 1, 0);  // [n=ci][c=t]
+        break;
+    }
+    return nsg_check_launch("pack_w_kernel");
+}
+
+size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d)
+{
+    if (!d) return 0;
+    const int kind = classify(d, "nsg_conv_workspace_bytes");
+    if (kind < 0) return 0;
+    const int T = d->k * d->k;
+    const int64_t Mp = lowres_pixels(d);
+    size_t bytes = 0;
+    int A, C, taps;
+    if (kind == K_CONV) { A = d->C_out; C = d->C_in; taps = T; }
+    else if (kind == K_CONVT) { A = d->C_in; C = d->C_out; taps = T; }
+    else if (kind == K_CONV_C1) { A = d->C_out; C = 16; taps = 1; bytes += patches_bytes(d); }
+    else { A = d->C_in; C = 16; taps = 1; bytes += patches_bytes(d); }
+    bytes += nsg_align_up(nsg_wgrad_workspace_bytes(Mp, taps, A, C), 256);
+    bytes += colsum_ws_bytes((int64_t)d->B * d->OH * d->OW, d->C_out);
+    return bytes;
+}
+
+int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y, int32_t flags,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int kind = classify(d, "nsg_conv_forward");
+    if (kind < 0) return kind;
+    NSG_REQUIRE(x && w_fwd && y, NSG_E_INVALID, "nsg_conv_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == K_CONV || kind == K_CONVT) {
+        GatherGemmParams p = {};
+        p.in = x; p.w = w_fwd; p.bias = bias; p.out = y;
+        p.B = d->B; p.IH = d->IH; p.IW = d->IW; p.CI = d->C_in;
+        p.OH = d->OH; p.OW = d->OW; p.CO = d->C_out;
+        p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
+        p.flags = flags & (NSG_RELU_IN | NSG_TANH_OUT);
+        if (kind == K_CONV) { p.mode = 0; p.RH = d->OH; p.RW = d->OW; }
+        else                { p.mode = 1; p.RH = d->IH; p.RW = d->IW; }
+        p.M = d->B * p.RH * p.RW;
+        return nsg_launch_gather_gemm(p, s);
+    }
+    NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward: workspace too small");
+    float *stage = reinterpret_cast<float *>(workspace);
+    const int64_t Mp = lowres_pixels(d);
+    if (kind == K_CONV_C1) {
+        NSG_REQUIRE(!(flags & NSG_RELU_IN), NSG_E_UNSUPPORTED, "nsg_conv_forward: NSG_RELU_IN on a single-channel input");
+        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, x, stage, d->B, d->OH, d->OW, d->IH, d->IW);
+        int rc = nsg_check_launch("im2col_c1_kernel");
+        if (rc) return rc;
+        return nsg_launch_gather_gemm(gg_1x1(stage, w_fwd, bias, y, Mp, 16, d->C_out, flags & NSG_TANH_OUT), s);
+    }
+    // K_CONVT_C1: per-input-pixel tap products, then the 4-tap gather with bias (+tanh)
+    int rc = nsg_launch_gather_gemm(gg_1x1(x, w_fwd, nullptr, stage, Mp, d->C_in, 16, flags & NSG_RELU_IN), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->OH * d->OW)), dim3(256), 0, s, stage, bias, y, d->B,
+                       d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0);
+    return nsg_check_launch("col2im_c1_kernel");
+}
+
+int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad, float *dx, int32_t flags, void *workspace,
+                   size_t workspace_bytes, void *stream)
+{
+    (void)flags;
+    const int kind = classify(d, "nsg_conv_dgrad");
+    if (kind < 0) return kind;
+    NSG_REQUIRE(dy && w_dgrad && dx, NSG_E_INVALID, "nsg_conv_dgrad: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == K_CONV || kind == K_CONVT) {
+        // roles swap: the gradient of a conv is a transposed conv and vice versa
+        GatherGemmParams p = {};
+        p.in = dy; p.w = w_dgrad; p.bias = nullptr; p.out = dx;
+        p.B = d->B; p.IH = d->OH; p.IW = d->OW; p.CI = d->C_out;
+        p.OH = d->IH; p.OW = d->IW; p.CO = d->C_in;
+        p.KH = d->k; p.KW = d->k;
+        p.flags = 0;
+        if (kind == K_CONV && d->stride == 1) {
+            p.mode = 0; p.stride = 1; p.pad = d->k - 1 - d->pad; p.RH = d->IH; p.RW = d->IW;  // flipped taps
+        } else if (kind == K_CONV) {
+            p.mode = 1; p.stride = 2; p.pad = 1; p.RH = (d->IH + 1) / 2; p.RW = (d->IW + 1) / 2;  // 4/2/1: transposed classes
+        } else {
+            p.mode = 0; p.stride = 2; p.pad = 1; p.RH = d->IH; p.RW = d->IW;  // gradient of convT = strided conv
+        }
+        p.M = d->B * p.RH * p.RW;
+        return nsg_launch_gather_gemm(p, s);
+    }
+    NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_dgrad: workspace too small");
+    float *stage = reinterpret_cast<float *>(workspace);
+    const int64_t Mp = lowres_pixels(d);
+    if (kind == K_CONVT_C1) {
+        // dx[pix][ci] = sum_t patch(dy)[pix][t] * w[ci][t]
+        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, dy, stage, d->B, d->IH, d->IW, d->OH, d->OW);
+        int rc = nsg_check_launch("im2col_c1_kernel");
+        if (rc) return rc;
+        return nsg_launch_gather_gemm(gg_1x1(stage, w_dgrad, nullptr, dx, Mp, 16, d->C_in, 0), s);
+    }
+    // K_CONV_C1: dots[pix][t] = sum_co dy[pix][co] * w[co][t], scattered back onto the image
+    int rc = nsg_launch_gather_gemm(gg_1x1(dy, w_dgrad, nullptr, stage, Mp, d->C_out, 16, 0), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->IH * d->IW)), dim3(256), 0, s, stage, nullptr, dx, d->B,
+                       d->OH, d->OW, d->IH, d->IW, 0);
+    return nsg_check_launch("col2im_c1_kernel");
+}
+
+int nsg_conv_wgrad(const nsg_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int32_t flags,
+                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int kind = classify(d, "nsg_conv_wgrad");
+    if (kind < 0) return kind;
+    NSG_REQUIRE(x && dy && dw, NSG_E_INVALID, "nsg_conv_wgrad: null pointer");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_conv_workspace_bytes(d), NSG_E_WORKSPACE, "nsg_conv_wgrad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace);
+    const int64_t Mp = lowres_pixels(d);
+    const int relu_x = (flags & NSG_RELU_IN) ? 1 : 0;
+    WgradParams p = {};
+    p.B = d->B; p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
+    p.Mp = (int)Mp;
+    float *stage = nullptr;
+    if (kind == K_CONV_C1 || kind == K_CONVT_C1) {
+        stage = reinterpret_cast<float *>(ws);
+        ws += patches_bytes(d);
+        p.B = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+        p.PH = 1; p.PW = (int)Mp; p.QH = 1; p.QW = (int)Mp; p.C = 16;
+    }
+    switch (kind) {
+    case K_CONV:
+        p.P = dy; p.PH = d->OH; p.PW = d->OW; p.A = d->C_out;
+        p.Q = x; p.QH = d->IH; p.QW = d->IW; p.C = d->C_in; p.relu_q = relu_x;
+        break;
+    case K_CONVT:
+        p.P = x; p.PH = d->IH; p.PW = d->IW; p.A = d->C_in; p.relu_p = relu_x;
+        p.Q = dy; p.QH = d->OH; p.QW = d->OW; p.C = d->C_out;
+        break;
+    case K_CONV_C1:
+        NSG_REQUIRE(!relu_x, NSG_E_UNSUPPORTED, "nsg_conv_wgrad: NSG_RELU_IN on a single-channel input");
+        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, x, stage, d->B, d->OH, d->OW, d->IH, d->IW);
+        p.P = dy; p.A = d->C_out; p.Q = stage;
+        break;
+    case K_CONVT_C1:
+        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, dy, stage, d->B, d->IH, d->IW, d->OH, d->OW);
+        p.P = x; p.A = d->C_in; p.relu_p = relu_x; p.Q = stage;
+        break;
+    }
+    const size_t wg_bytes = nsg_align_up(nsg_wgrad_workspace_bytes(Mp, p.KH * p.KW, p.A, p.C), 256);
+    int rc = nsg_launch_wgrad(p, dw, ws, wg_bytes, s);
+    if (rc) return rc;
+    ws += wg_bytes;
+    if (dbias) return colsum(dy, (int64_t)d->B * d->OH * d->OW, d->C_out, dbias, ws, s);
+    return NSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// Implicit-GEMM convolution forward / data-gradient on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+//   out[pixel(m)][n] = bias[n] + sum over taps t, channels c of  in[pixel(m) shifted by tap t][c] * w[slice(t)][n][c]
+//
+// One kernel serves nn.Conv2d forward, nn.ConvTranspose2d forward and both of their data
+// gradients (reference call sites: src/models.py:150,153,165,168,179,182 and their autograd):
+//   mode 0 ("conv gather"):   input pixel = (ry*stride - pad + kh, rx*stride - pad + kw)
+//   mode 1 ("transposed 4/2/1"): the 4 output parity classes (oy&1, ox&1) each use their own 2x2
+//       subset of the 4x4 taps; one class per blockIdx.y, so every row of a tile shares its taps.
+//
+// Layout / mapping (MI355X-first, not a port of anything):
+//   * activations NHWC, so a K-chunk (32 channels of one tap) of a row is 128 contiguous bytes;
+//   * block = 256 threads = 4 waves, tile BM x BN = (WM*TM*32) x (WN*TN*32), each wave owns
+//     TM x TN accumulators of 32x32 (v16f each);
+//   * A (gathered input rows) and B (weights, [n][c] so both operands are "row = MFMA row/col,
+//     contiguous k") are register-staged global -> LDS with a 36-float row pitch: the
+//     ds_read_b128 of 16 different rows then lands on 16 different 4-bank groups (conflict-free);
+//   * one lane's ds_read_b128 feeds 4 MFMAs: MFMA q of a chunk-of-8 consumes k = {q, 4+q}
+//     (lane half h supplies k = 4h+q) for both operands, which is a fixed permutation of the
+//     reduction order, identical on both sides;
+//   * double-buffered LDS, next chunk's global loads are issued before the MFMAs of the current.
+#include "nsg_common.h"
+
+namespace {
+
+constexpr int LDS_PITCH = 36;  // floats per staged row (32 + 4 pad)
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
+{
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int AJ = BM / 32;  // float4 rows per thread for A
+    constexpr int BJ = BN / 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                         // [2][BM][36]
+    float *Bs = smem + 2 * BM * LDS_PITCH;    // [2][BN][36]
+    int *rowoff = reinterpret_cast<int *>(Bs + 2 * BN * LDS_PITCH);  // [BM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int ntiles_n = (p.CO + BN - 1) / BN;
+    const int mtile = blockIdx.x / ntiles_n;
+    const int ntile = blockIdx.x % ntiles_n;
+    const int m0 = mtile * BM;
+    const int n0 = ntile * BN;
+    const int cls = blockIdx.y;
+    const int py = cls >> 1, px = cls & 1;
+
+    // ---- per-thread gather rows: row r_j = tid/8 + 32 j ----
+    const int c4 = (tid & 7) * 4;
+    const int rsub = tid >> 3;
+    int rbase[AJ];  // element offset of (b, iy0, ix0, 0); may be "negative pixel", guarded by iy/ix tests
+    int riy0[AJ], rix0[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + rsub + 32 * j;
+        if (m < p.M) {
+            const int b = m / (p.RH * p.RW);
+            const int rem = m - b * (p.RH * p.RW);
+            const int ry = rem / p.RW;
+            const int rx = rem - ry * p.RW;
+            int iy0, ix0;
+            if (p.mode == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad; }
+            else             { iy0 = ry + py;               ix0 = rx + px; }
+            riy0[j] = iy0;
+            rix0[j] = ix0;
+            rbase[j] = ((b * p.IH + iy0) * p.IW + ix0) * p.CI;
+        } else {
+            riy0[j] = -(1 << 28);  // never in range
+            rix0[j] = -(1 << 28);
+            rbase[j] = 0;
+        }
+    }
+    // ---- output row offsets ----
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < p.M) {
+            const int b = m / (p.RH * p.RW);
+            const int rem = m - b * (p.RH * p.RW);
+            const int ry = rem / p.RW;
+            const int rx = rem - ry * p.RW;
+            const int oy = (p.mode == 0) ? ry : 2 * ry + py;
+            const int ox = (p.mode == 0) ? rx : 2 * rx + px;
+            if (oy < p.OH && ox < p.OW) off = ((b * p.OH + oy) * p.OW + ox) * p.CO;  // odd extents: last class row/col absent
+        }
+        rowoff[tid] = off;
+    }
+
+    const int nchunks = (p.CI + 31) >> 5;
+    const int ntaps = (p.mode == 0) ? p.KH * p.KW : 4;
+    const int nit = ntaps * nchunks;
+    const bool relu_in = (p.flags & NSG_RELU_IN) != 0;
+
+    v4f ra[AJ], rb[BJ];
+
+    auto gload = [&](int it) {
+        const int t = it / nchunks;
+        const int c0 = (it - t * nchunks) << 5;
+        int dy, dx, ws;
+        if (p.mode == 0) {
+            dy = t / p.KW;
+            dx = t - dy * p.KW;
+            ws = t;
+        } else {
+            const int a = t >> 1, b2 = t & 1;
+            dy = -a;
+            dx = -b2;
+            ws = ((1 - py) + 2 * a) * 4 + (1 - px) + 2 * b2;
+        }
+        const int tapoff = (dy * p.IW + dx) * p.CI + c0 + c4;
+        const bool cok = (c0 + c4) < p.CI;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int iy = riy0[j] + dy, ix = rix0[j] + dx;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+                v = *reinterpret_cast<const v4f *>(p.in + (rbase[j] + tapoff));
+            if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int n = n0 + rsub + 32 * j;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && n < p.CO)
+                v = *reinterpret_cast<const v4f *>(p.w + ((size_t)(ws * p.CO + n) * p.CI + c0 + c4));
+            rb[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *a = As + buf * BM * LDS_PITCH;
+        float *b = Bs + buf * BN * LDS_PITCH;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + c4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + c4) = rb[j];
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nit) gload(it + 1);
+        const float *a_base = As + cur * BM * LDS_PITCH + (wr * TM * 32 + l31) * LDS_PITCH + 4 * h;
+        const float *b_base = Bs + cur * BN * LDS_PITCH + (wc * TN * 32 + l31) * LDS_PITCH + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v4f a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v4f *>(a_base + i * 32 * LDS_PITCH + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const v4f *>(b_base + j * 32 * LDS_PITCH + kk * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nit) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * TN * 32 + j * 32 + l31;
+        if (col >= p.CO) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int off = rowoff[row];
+                if (off >= 0) {
+                    float v = acc[i][j][r] + bv;
+                    if (tanh_out) v = tanhf(v);
+                    p.out[(size_t)off + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const GatherGemmParams &p, hipStream_t s)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const size_t lds = (size_t)(2 * BM * LDS_PITCH + 2 * BN * LDS_PITCH) * sizeof(float) + BM * sizeof(int);
+    const int ntn = (p.CO + BN - 1) / BN;
+    const int64_t ntm = nsg_cdiv(p.M, BM);
+    const int64_t gx = ntm * ntn;
+    if (gx <= 0 || gx > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: grid too large");
+    dim3 grid((unsigned)gx, p.mode == 0 ? 1 : 4, 1);
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
+    if (!attr_set && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_gemm_f32<WM, WN, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return nsg_fail((int)e, "gather_gemm: cannot reserve %zu bytes of LDS", lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gather_gemm_f32<WM, WN, TM, TN>), grid, dim3(256), lds, s, p);
+    return nsg_check_launch("gather_gemm_f32");
+}
+
+}  // namespace
+
+int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s)
+{
+    if (p.M <= 0) return NSG_OK;
+    if (p.CI % 4 != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of 4", p.CI);
+    if (!nsg_aligned16(p.in) || !nsg_aligned16(p.w)) return nsg_fail(NSG_E_INVALID, "gather_gemm: operands must be 16-byte aligned");
+    if (p.CO > 64) return launch_cfg<2, 2, 2, 2>(p, s);   // 128 x 128
+    if (p.CO > 32) return launch_cfg<2, 2, 2, 1>(p, s);   // 128 x 64
+    return launch_cfg<4, 1, 1, 1>(p, s);                  // 128 x 32
+}

@@ -1,0 +1,59 @@
+// Internal helpers shared by the kernels of libnsg.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "nsg.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// thread-local error text (never thrown across the ABI)
+void nsg_set_error(const char *fmt, ...);
+int nsg_fail(int code, const char *fmt, ...);
+int nsg_check_launch(const char *what);
+
+#define NSG_REQUIRE(cond, code, ...)                    \
+    do {                                                \
+        if (!(cond)) return nsg_fail((code), __VA_ARGS__); \
+    } while (0)
+
+static inline bool nsg_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool nsg_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t nsg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t nsg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- implicit-GEMM parameter blocks (gemm_gather.hip / gemm_wgrad.hip) -------------------------
+struct GatherGemmParams {
+    const float *in;    // [B][IH][IW][CI]
+    const float *w;     // [tap image][CO][CI]
+    const float *bias;  // [CO] or null
+    float *out;         // [B][OH][OW][CO]
+    int B, IH, IW, CI;
+    int OH, OW, CO;
+    int KH, KW, stride, pad;
+    int mode;    // 0: conv gather (iy = ry*stride - pad + kh); 1: transposed 4/2/1, one parity class per blockIdx.y
+    int M;       // rows per class = B*RH*RW
+    int RH, RW;  // row grid: conv -> (OH,OW); transposed -> (ceil(OH/2), ceil(OW/2))
+    int flags;   // NSG_RELU_IN | NSG_TANH_OUT
+};
+
+struct WgradParams {
+    const float *P;      // [B][PH][PW][A]  tensor on the conv-OUTPUT pixel grid (rows of the reduction)
+    const float *Q;      // [B][QH][QW][C]  tensor on the conv-INPUT pixel grid, gathered per tap
+    const int64_t *idx;  // one-hot mode: P[pix][a] = (idx[pix] == a)
+    float *partial;      // [nslab][ntaps][A][C]
+    int B, PH, PW, A;
+    int QH, QW, C;
+    int KH, KW, stride, pad;
+    int Mp;         // B*PH*PW
+    int slab_rows;  // multiple of 32
+    int relu_p, relu_q, onehot;
+};
+
+int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
+// Returns bytes of partial-slab workspace it will use for these sizes.
+size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C);
+// dst[(a*C + c)*ntaps + t] = sum over slabs (fixed order) of partial; dst fully overwritten.
+int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,485 @@
+// Vector quantiser kernels (gfx950): fused ||x-e||^2 nearest-code search with a bit-exact argmin,
+// code gather, codebook scatter-add, EMA update.   Reference: src/vector_quantization.py:6-66,
+// src/models.py:132-142.
+//
+// Bit-exactness (DESIGN.md "bit-exact argmin"): the reference's CPU result is, entry by entry,
+//     dist[i][k] = fl( fl(c2[k] + x2[i]) - 2*dot[i][k] ),   dot = fmaf chain over d = 0..D-1 from +0,
+// with c2/x2 summed in ATen's vector-lane order, and torch.min keeps the first minimal index.
+// v_mfma_f32_32x32x2_f32 IS a k-ordered fmaf chain (one rounding per product, no wider
+// accumulator), so feeding it d = 2s (lanes 0-31) and d = 2s+1 (lanes 32-63) at step s reproduces
+// the chain exactly on the matrix pipe.  tests/test_gpu_vq.py checks MFMA == VALU chain bit for bit
+// (nsg_debug_dot) and the indices against fixtures generated from the reference.
+#include "nsg_common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// torch.sum(v**2, dim=1) in ATen's CPU order: 8 vector lanes x 4 interleaved accumulators.
+// 8 threads per row: thread l plays vector lane l.
+// ------------------------------------------------------------------------------------------------
+__global__ void rowsumsq_kernel(const float *__restrict__ v, int64_t rows, int D, float *__restrict__ out)
+{
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t row = gid >> 3;
+    const int l = (int)(gid & 7);
+    const bool live = row < rows;
+    const float *p = v + (live ? row : 0) * (int64_t)D;
+    const int nvec = D >> 3, ngrp = nvec >> 2;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < ngrp; ++c) {
+        const float v0 = p[(4 * c + 0) * 8 + l], v1 = p[(4 * c + 1) * 8 + l];
+        const float v2 = p[(4 * c + 2) * 8 + l], v3 = p[(4 * c + 3) * 8 + l];
+        a0 = __fadd_rn(a0, __fmul_rn(v0, v0));
+        a1 = __fadd_rn(a1, __fmul_rn(v1, v1));
+        a2 = __fadd_rn(a2, __fmul_rn(v2, v2));
+        a3 = __fadd_rn(a3, __fmul_rn(v3, v3));
+    }
+    for (int i = ngrp * 4; i < nvec; ++i) {
+        const float v0 = p[i * 8 + l];
+        a0 = __fadd_rn(a0, __fmul_rn(v0, v0));
+    }
+    const float a = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+    float fin = 0.f;
+    for (int k = nvec * 8; k < D; ++k) fin = __fadd_rn(fin, __fmul_rn(p[k], p[k]));
+    const int base = threadIdx.x & ~7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fin = __fadd_rn(fin, __shfl(a, (base + j) & 63, 64));
+    if (live && l == 0) out[row] = fin;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused search.  Block = 4 waves = 128 rows (32 per wave); codes streamed in tiles of 32 through
+// double-buffered LDS; each wave keeps its 32 rows of x in DP/2 registers as MFMA A fragments.
+// ------------------------------------------------------------------------------------------------
+template <int DP, bool USE_MFMA>
+__global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict__ x, const float *__restrict__ e,
+                                                         const float *__restrict__ x2, const float *__restrict__ c2,
+                                                         int64_t N, int D, int K, int64_t *__restrict__ idx_out,
+                                                         float *__restrict__ codes_out, float *__restrict__ dmin_out)
+{
+    constexpr int NS = DP / 2;           // MFMA steps (2 d's per step)
+    constexpr int EP = DP + 1;           // LDS pitch of a code row (odd: conflict-free ds_read_b32)
+    constexpr int XC = (DP < 64) ? DP : 64;  // x staging chunk (d's)
+    constexpr int XP = XC + 1;
+    constexpr int EJ = (32 * DP / 4 + 255) / 256;  // float4 per thread per code tile
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Es = smem;                                   // [2][32][EP]   (also x staging: [128][XP])
+    __shared__ int sidx[128];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const bool vec_ok = (D & 3) == 0 && nsg_aligned16_dev(e);
+
+    // ---- x rows -> A fragments: a[s] = x[row0 + wave*32 + l31][2s + h] ----
+    float a[NS];
+    {
+        float *Xs = smem;  // [128][XP]
+#pragma unroll
+        for (int c = 0; c < DP / XC; ++c) {
+            const int d0 = c * XC;
+            for (int f = tid; f < 128 * XC; f += 256) {
+                const int r = f / XC, dd = f - r * XC;
+                const int64_t row = row0 + r;
+                const int d = d0 + dd;
+                Xs[r * XP + dd] = (row < N && d < D) ? x[row * D + d] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < XC / 2; ++s) a[c * (XC / 2) + s] = Xs[(wave * 32 + l31) * XP + 2 * s + h];
+            __syncthreads();
+        }
+    }
+
+    // rows this lane's accumulator registers belong to, and their ||x||^2
+    float x2v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        x2v[r] = row < N ? x2[row] : 0.f;
+    }
+    float best[16];
+    int bidx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = INFINITY; bidx[r] = 0x7fffffff; }
+
+    const int ntiles = (K + 31) / 32;
+    v4f re[EJ];
+    auto gload = [&](int ct) {
+#pragma unroll
+        for (int j = 0; j < EJ; ++j) {
+            const int f = tid + 256 * j;       // float4 index inside the [32][DP] tile
+            const int cr = f / (DP / 4), d4 = (f - cr * (DP / 4)) * 4;
+            const int code = ct * 32 + cr;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (cr < 32 && code < K) {
+                const float *src = e + (size_t)code * D + d4;
+                if (vec_ok && d4 + 3 < D) v = *reinterpret_cast<const v4f *>(src);
+                else {
+                    if (d4 + 0 < D) v.x = src[0];
+                    if (d4 + 1 < D) v.y = src[1];
+                    if (d4 + 2 < D) v.z = src[2];
+                    if (d4 + 3 < D) v.w = src[3];
+                }
+            }
+            re[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *es = Es + buf * 32 * EP;
+#pragma unroll
+        for (int j = 0; j < EJ; ++j) {
+            const int f = tid + 256 * j;
+            const int cr = f / (DP / 4), d4 = (f - cr * (DP / 4)) * 4;
+            if (cr < 32) {
+                float *dst = es + cr * EP + d4;
+                dst[0] = re[j].x; dst[1] = re[j].y; dst[2] = re[j].z; dst[3] = re[j].w;
+            }
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int ct = 0; ct < ntiles; ++ct) {
+        const int cur = ct & 1;
+        if (ct + 1 < ntiles) gload(ct + 1);
+        const int code = ct * 32 + l31;
+        const float c2v = code < K ? c2[code] : INFINITY;
+        const float *es = Es + cur * 32 * EP + l31 * EP + h;
+
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (USE_MFMA) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], es[2 * s], acc, 0, 0, 0);
+        } else {
+            // cross-check path: the same dot products as explicit fmaf chains on the vector ALU.
+            // Lane (l31,h) needs x[row(r,h)][d] for every d: fetched from the lanes that hold it.
+            const float *eb = Es + cur * 32 * EP + l31 * EP;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float e0 = eb[2 * s], e1 = eb[2 * s + 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int src_row = (r & 3) + 8 * (r >> 2) + 4 * h;  // row inside the wave's 32
+                    const float xe = __shfl(a[s], src_row, 64);        // d = 2s   (held by lane src_row)
+                    const float xo = __shfl(a[s], src_row + 32, 64);   // d = 2s+1 (held by lane src_row+32)
+                    acc[r] = __fmaf_rn(xo, e1, __fmaf_rn(xe, e0, acc[r]));
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float base = __fadd_rn(c2v, x2v[r]);
+            const float dist = __fmaf_rn(-2.0f, acc[r], base);  // -2*dot is exact: one rounding, as addmm's epilogue
+            if (dist < best[r]) { best[r] = dist; bidx[r] = code; }
+        }
+        if (ct + 1 < ntiles) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- first-minimum across the 32 lanes (codes) of each half; xor < 32 stays inside the half ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float bv = best[r];
+        int bi = bidx[r];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        if (l31 == 0) {
+            const int rl = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t row = row0 + rl;
+            sidx[rl] = bi;
+            if (row < N) {
+                idx_out[row] = (int64_t)bi;
+                if (dmin_out) dmin_out[row] = bv;
+            }
+        }
+    }
+    if (codes_out == nullptr) return;
+    __syncthreads();
+    // ---- gather: codes_out[row] = e[idx[row]]  (vector_quantization.py:40-42) ----
+    if (vec_ok && nsg_aligned16_dev(codes_out)) {
+        const int D4 = D >> 2;
+        for (int f = tid; f < 128 * D4; f += 256) {
+            const int r = f / D4, d4 = (f - r * D4) * 4;
+            const int64_t row = row0 + r;
+            if (row < N)
+                *reinterpret_cast<v4f *>(codes_out + row * D + d4) = *reinterpret_cast<const v4f *>(e + (size_t)sidx[r] * D + d4);
+        }
+    } else {
+        for (int f = tid; f < 128 * D; f += 256) {
+            const int r = f / D, d = f - r * D;
+            const int64_t row = row0 + r;
+            if (row < N) codes_out[row * D + d] = e[(size_t)sidx[r] * D + d];
+        }
+    }
+}
+
+// dot products only, same fragment order as above (nsg_debug_dot)
+template <bool USE_MFMA>
+__global__ __launch_bounds__(64) void debug_dot_kernel(const float *x, const float *e, int N, int D, int K, float *out)
+{
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    if (USE_MFMA) {
+        v16f acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int s = 0; s < (D + 1) / 2; ++s) {
+            const int d = 2 * s + h;
+            const float av = d < D ? x[(size_t)(r0 + l31) * D + d] : 0.f;
+            const float bv = d < D ? e[(size_t)(k0 + l31) * D + d] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)row * K + k0 + l31] = acc[r];
+        }
+    } else {
+        for (int rr = h; rr < 32; rr += 2) {
+            float c = 0.f;
+            for (int d = 0; d < D; ++d) c = __fmaf_rn(x[(size_t)(r0 + rr) * D + d], e[(size_t)(k0 + l31) * D + d], c);
+            out[(size_t)(r0 + rr) * K + k0 + l31] = c;
+        }
+    }
+}
+
+// out[i][:] = e[idx[i]][:]
+__global__ void gather_rows_kernel(const float *__restrict__ e, const int64_t *__restrict__ idx, int64_t N, int D, int K,
+                                   float *__restrict__ out, int vec)
+{
+    if (vec) {
+        const int D4 = D >> 2;
+        const int64_t total = N * D4;
+        for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < total; f += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = f / D4;
+            const int d4 = (int)(f - r * D4) * 4;
+            int64_t k = idx[r];
+            k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+            *reinterpret_cast<v4f *>(out + r * D + d4) = *reinterpret_cast<const v4f *>(e + k * D + d4);
+        }
+    } else {
+        const int64_t total = N * D;
+        for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < total; f += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = f / D;
+            const int d = (int)(f - r * D);
+            int64_t k = idx[r];
+            k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+            out[f] = e[k * D + d];
+        }
+    }
+}
+
+__global__ void count_codes_kernel(const int64_t *idx, int64_t N, int K, int *counts)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = idx[i];
+        if (k >= 0 && k < K) atomicAdd(&counts[k], 1);
+    }
+}
+__global__ void counts_to_float_kernel(const int *counts, int K, float *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) out[k] = (float)counts[k];
+}
+
+// EMA codebook update (extension).  Kernel 1 (one block): decay the counts and form their total in a
+// fixed order, so every rank / launch computes the identical value.  Kernel 2: the K x D part.
+__global__ void ema_counts_kernel(float *ema_n, const float *n, int K, float decay, float *total)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double part = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const float v = decay * ema_n[k] + (1.f - decay) * n[k];
+        ema_n[k] = v;
+        part += (double)v;
+    }
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += red[i];
+        total[0] = (float)t;
+    }
+}
+__global__ void ema_codes_kernel(float *e, const float *ema_n, float *ema_s, const float *s, int K, int D, float decay,
+                                 float eps, const float *total)
+{
+    const float tot = total[0];
+    const int64_t n = (int64_t)K * D;
+    for (int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; f < n; f += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(f / D);
+        const float sv = decay * ema_s[f] + (1.f - decay) * s[f];
+        ema_s[f] = sv;
+        const float nn = (ema_n[k] + eps) / (tot + K * eps) * tot;
+        e[f] = sv / nn;
+    }
+}
+
+template <int DP>
+int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const float *c2, int64_t N, int D, int K,
+              int64_t *idx, float *codes, float *dmin, hipStream_t s)
+{
+    constexpr int XC = (DP < 64) ? DP : 64;
+    const size_t lds_e = (size_t)2 * 32 * (DP + 1) * sizeof(float);
+    const size_t lds_x = (size_t)128 * (XC + 1) * sizeof(float);
+    const size_t lds = lds_e > lds_x ? lds_e : lds_x;
+    const int64_t nb = nsg_cdiv(N, 128);
+    if (nb > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "vq_forward: too many rows");
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536 - 1024) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_forward_kernel<DP, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_forward_kernel<DP, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return nsg_fail((int)(e1 != hipSuccess ? e1 : e2), "vq_forward: cannot reserve %zu bytes of LDS", lds);
+        attr_set = true;
+    }
+    if (mfma)
+        hipLaunchKernelGGL((vq_forward_kernel<DP, true>), dim3((unsigned)nb), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin);
+    else
+        hipLaunchKernelGGL((vq_forward_kernel<DP, false>), dim3((unsigned)nb), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin);
+    return nsg_check_launch("vq_forward_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nsg_vq_workspace_bytes(int64_t N, int32_t D, int32_t K)
+{
+    (void)D;
+    if (N < 0 || K < 0) return 0;
+    return nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256);
+}
+
+int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream)
+{
+    NSG_REQUIRE(v && out && rows >= 0 && D > 0, NSG_E_INVALID, "nsg_rowsumsq: bad argument");
+    if (rows == 0) return NSG_OK;
+    const int64_t nb = nsg_cdiv(rows * 8, 256);
+    NSG_REQUIRE(nb <= 0x7fffffff, NSG_E_UNSUPPORTED, "nsg_rowsumsq: too many rows");
+    hipLaunchKernelGGL(rowsumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, v, rows, D, out);
+    return nsg_check_launch("rowsumsq_kernel");
+}
+
+static int vq_forward_impl(bool mfma, const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+                           float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(x && e && idx_out && N >= 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_vq_forward: bad argument");
+    NSG_REQUIRE(D <= 256, NSG_E_UNSUPPORTED, "nsg_vq_forward: D=%d > 256 is not supported", D);
+    if (N == 0) return NSG_OK;
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_vq_workspace_bytes(N, D, K), NSG_E_WORKSPACE,
+                "nsg_vq_forward: workspace too small");
+    float *x2 = reinterpret_cast<float *>(workspace);
+    float *c2 = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + nsg_align_up((size_t)N * sizeof(float), 256));
+    int rc = nsg_rowsumsq(x, N, D, x2, stream);
+    if (rc) return rc;
+    rc = nsg_rowsumsq(e, K, D, c2, stream);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (D <= 16) return launch_vq<16>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+    if (D <= 32) return launch_vq<32>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+    if (D <= 64) return launch_vq<64>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+    if (D <= 128) return launch_vq<128>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+    return launch_vq<256>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+}
+
+int nsg_vq_forward(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out, float *codes_out,
+                   float *dmin_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return vq_forward_impl(true, x, e, N, D, K, idx_out, codes_out, dmin_out, workspace, workspace_bytes, stream);
+}
+
+// not in nsg.h: the vector-ALU cross-check build of the same kernel (tests only)
+NSG_API int nsg_debug_vq_forward_valu(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+                                      float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes,
+                                      void *stream)
+{
+    return vq_forward_impl(false, x, e, N, D, K, idx_out, codes_out, dmin_out, workspace, workspace_bytes, stream);
+}
+
+int nsg_debug_dot(const float *x, const float *e, int32_t N, int32_t D, int32_t K, int32_t mode, float *out, void *stream)
+{
+    NSG_REQUIRE(x && e && out && N > 0 && K > 0 && D > 0 && D <= 256 && N % 32 == 0 && K % 32 == 0, NSG_E_INVALID,
+                "nsg_debug_dot: bad argument");
+    dim3 grid(N / 32, K / 32);
+    if (mode == 1) hipLaunchKernelGGL((debug_dot_kernel<true>), grid, dim3(64), 0, (hipStream_t)stream, x, e, N, D, K, out);
+    else           hipLaunchKernelGGL((debug_dot_kernel<false>), grid, dim3(64), 0, (hipStream_t)stream, x, e, N, D, K, out);
+    return nsg_check_launch("debug_dot_kernel");
+}
+
+size_t nsg_index_add_workspace_bytes(int64_t N, int32_t D, int32_t K)
+{
+    if (N <= 0 || D <= 0 || K <= 0) return 0;
+    return nsg_align_up((size_t)K * sizeof(int), 256) + nsg_wgrad_workspace_bytes(N, 1, K, D);
+}
+
+int nsg_index_add_rows(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out, float *counts_out,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(idx && g && out && N > 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_index_add_rows: bad argument");
+    NSG_REQUIRE(N < 0x7fffffff, NSG_E_UNSUPPORTED, "nsg_index_add_rows: too many rows");
+    NSG_REQUIRE(D % 4 == 0, NSG_E_UNSUPPORTED, "nsg_index_add_rows: D=%d must be a multiple of 4", D);
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_index_add_workspace_bytes(N, D, K), NSG_E_WORKSPACE,
+                "nsg_index_add_rows: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t cnt_bytes = nsg_align_up((size_t)K * sizeof(int), 256);
+    if (counts_out) {
+        int *cnt = reinterpret_cast<int *>(workspace);
+        hipError_t err = hipMemsetAsync(cnt, 0, (size_t)K * sizeof(int), s);
+        if (err != hipSuccess) return nsg_fail((int)err, "nsg_index_add_rows: memset failed");
+        const int nb = (int)(nsg_cdiv(N, 256) > 1024 ? 1024 : nsg_cdiv(N, 256));
+        hipLaunchKernelGGL(count_codes_kernel, dim3(nb), dim3(256), 0, s, idx, N, K, cnt);
+        hipLaunchKernelGGL(counts_to_float_kernel, dim3((K + 255) / 256), dim3(256), 0, s, cnt, K, counts_out);
+        int rc = nsg_check_launch("count_codes_kernel");
+        if (rc) return rc;
+    }
+    WgradParams p = {};
+    p.P = nullptr;
+    p.Q = g;
+    p.idx = idx;
+    p.B = 1; p.PH = 1; p.PW = (int)N; p.A = K;
+    p.QH = 1; p.QW = (int)N; p.C = D;
+    p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.Mp = (int)N;
+    p.onehot = 1;
+    return nsg_launch_wgrad(p, out, reinterpret_cast<char *>(workspace) + cnt_bytes, workspace_bytes - cnt_bytes, s);
+}
+
+int nsg_gather_rows(const float *e, const int64_t *idx, int64_t N, int32_t D, int32_t K, float *out, void *stream)
+{
+    NSG_REQUIRE(e && idx && out && N >= 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_gather_rows: bad argument");
+    if (N == 0) return NSG_OK;
+    const int vec = (D % 4 == 0) && nsg_aligned16(e) && nsg_aligned16(out);
+    const int64_t work = vec ? N * (D / 4) : N * (int64_t)D;
+    const int nb = (int)(nsg_cdiv(work, 256) > 4096 ? 4096 : nsg_cdiv(work, 256));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e, idx, N, D, K, out, vec);
+    return nsg_check_launch("gather_rows_kernel");
+}
+
+int nsg_vq_ema_update(float *e, float *ema_n, float *ema_s, const float *n, const float *s, int32_t K, int32_t D,
+                      float decay, float eps, float *scratch, void *stream)
+{
+    NSG_REQUIRE(e && ema_n && ema_s && n && s && K > 0 && D > 0, NSG_E_INVALID, "nsg_vq_ema_update: bad argument");
+    NSG_REQUIRE(scratch, NSG_E_INVALID, "nsg_vq_ema_update: scratch (1 float) required");
+    hipLaunchKernelGGL(ema_counts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ema_n, n, K, decay, scratch);
+    const int64_t tot = (int64_t)K * D;
+    const int nb = (int)(nsg_cdiv(tot, 256) > 2048 ? 2048 : nsg_cdiv(tot, 256));
+    hipLaunchKernelGGL(ema_codes_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, e, ema_n, ema_s, s, K, D, decay, eps, scratch);
+    return nsg_check_launch("ema_update");
+}
+
+}  // extern "C"

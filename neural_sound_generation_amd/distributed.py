@@ -1,0 +1,56 @@
+"""Single-node data parallelism: one process per GPU, model replicated, minibatch sharded by clips,
+ONE all-reduce (sum) of the flat gradient bucket per step over RCCL/xGMI (torch.distributed backend
+"nccl" is RCCL on ROCm), 1/world_size folded into the optimiser kernel.
+
+The reference has no DDP wiring at all; the semantics implemented are plain
+DDP's: per-rank BatchNorm statistics, gradients averaged over ranks, identical update everywhere.
+Messages are small (5 MB at D=128) and latency-bound, hence one bucket, one collective.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).
+    Returns (rank, world_size, local_rank); a no-op single-process setup when WORLD_SIZE is unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_flat(flat: torch.Tensor, src: int = 0, group=None):
+    """Make every replica start from rank `src`'s parameters."""
+    if world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None, async_op: bool = False):
+    """In-place sum over ranks of one flat bucket; returns the work handle when async."""
+    if world_size(group) == 1:
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def shard_batch(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank r takes clips [r*B/world, (r+1)*B/world) of the global batch."""
+    if batch.size(0) % world != 0:
+        raise ValueError(f"global batch {batch.size(0)} is not divisible by world size {world}")
+    per = batch.size(0) // world
+    return batch[rank * per:(rank + 1) * per]

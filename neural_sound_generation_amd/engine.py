@@ -1,0 +1,220 @@
+"""Explicit forward / backward of the VQ-VAE encoder, decoder and ResBlock over NHWC buffers.
+
+This is the static "graph" of the hot path (reference: src/models.py:145-216), written as straight
+sequences of C-ABI kernel calls with the fusion decisions made by hand:
+  * the ReLU that heads a ResBlock / precedes a conv is fused into that conv's operand load;
+  * BatchNorm normalise + ReLU (+ the ResBlock skip add of the ReLU'd input) is one kernel;
+  * BatchNorm backward folds the ReLU mask; the ResBlock's input gradient folds add + ReLU mask.
+No autograd runs inside; neural_sound_generation_amd.functional wraps these pieces in
+torch.autograd.Function so they compose with user code, and train.py drives them directly.
+
+Parameter bundles are plain tuples of tensors in the reference's state_dict order.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import NSG_RELU_IN, NSG_TANH_OUT
+
+
+@dataclass
+class BNParams:
+    weight: torch.Tensor
+    bias: torch.Tensor
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+    num_batches_tracked: Optional[torch.Tensor] = None
+
+
+@dataclass
+class ConvParams:
+    weight: torch.Tensor
+    bias: torch.Tensor
+
+
+@dataclass
+class ResBlockParams:
+    conv1: ConvParams   # block.1  3x3
+    bn1: BNParams       # block.2
+    conv2: ConvParams   # block.4  1x1
+    bn2: BNParams       # block.5
+
+
+@dataclass
+class EncoderParams:
+    conv0: ConvParams   # encoder.0  Conv2d(1, D, 4, 2, 1)
+    bn0: BNParams       # encoder.1
+    conv3: ConvParams   # encoder.3  Conv2d(D, D, 4, 2, 1)
+    res4: ResBlockParams
+    res5: ResBlockParams
+
+
+@dataclass
+class DecoderParams:
+    res0: ResBlockParams
+    res1: ResBlockParams
+    convt3: ConvParams  # decoder.3  ConvTranspose2d(D, D, 4, 2, 1)
+    bn4: BNParams       # decoder.4
+    convt6: ConvParams  # decoder.6  ConvTranspose2d(D, 1, 4, 2, 1)
+
+
+def _bn_forward(h, bn: BNParams, training: bool):
+    C = bn.weight.numel()
+    if training:
+        mean, invstd = ops.bn_stats(h, C, bn.running_mean, bn.running_var)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    else:
+        mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var)
+    return mean, invstd
+
+
+# ------------------------------------------------------------------------------------------------
+# ResBlock   y = relu(x) + BN(conv1x1(relu(BN(conv3x3(relu(x))))))      (src/models.py:145-158)
+# ------------------------------------------------------------------------------------------------
+def resblock_forward(x, P: ResBlockParams, training: bool):
+    B, H, W, D = x.shape
+    d1 = ops.conv_desc(B, H, W, D, D, 3, 1, 1)
+    d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0)
+    wf1, wd1 = ops.pack_weights(d1, P.conv1.weight)
+    wf2, wd2 = ops.pack_weights(d2, P.conv2.weight)
+    h1 = ops.conv_forward(d1, x, wf1, P.conv1.bias, flags=NSG_RELU_IN)
+    m1, i1 = _bn_forward(h1, P.bn1, training)
+    a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
+    h2 = ops.conv_forward(d2, a1, wf2, P.conv2.bias)
+    m2, i2 = _bn_forward(h2, P.bn2, training)
+    y = ops.bn_apply(h2, m2, i2, P.bn2.weight, P.bn2.bias, relu=False, residual=x, relu_residual=True)
+    saved = (x, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2)
+    return y, saved
+
+
+def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=None):
+    """Returns (dx, grads) with grads in the order conv1.w, conv1.b, bn1.w, bn1.b, conv2.w, conv2.b, bn2.w, bn2.b.
+    gout: optional list of 8 preallocated tensors (e.g. views of a flat gradient bucket) to write into."""
+    x, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2 = saved
+    o = gout if gout is not None else [None] * 8
+    dh2, dg2, db2n = ops.bn_backward(h2, None, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7])
+    dw2, dbias2 = ops.conv_wgrad(d2, a1, dh2, P.conv2.weight.shape, dw=o[4], dbias=o[5])
+    da1 = ops.conv_dgrad(d2, dh2, wd2)
+    dh1, dg1, db1n = ops.bn_backward(h1, a1, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3])
+    dw1, dbias1 = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, flags=NSG_RELU_IN, dw=o[0], dbias=o[1])
+    dx = None
+    if need_dx:
+        dr = ops.conv_dgrad(d1, dh1, wd1)
+        dx = ops.relu_backward_add(dy, dr, x)
+    return dx, [dw1, dbias1, dg1, db1n, dw2, dbias2, dg2, db2n]
+
+
+# ------------------------------------------------------------------------------------------------
+# Encoder   (src/models.py:164-171)
+# ------------------------------------------------------------------------------------------------
+def encoder_forward(x, P: EncoderParams, training: bool):
+    """x NHWC (B, H, W, 1) -> z_e NHWC (B, H/4, W/4, D)."""
+    B, H, W, _ = x.shape
+    D = P.conv0.weight.shape[0]
+    d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1)
+    wf0, _ = ops.pack_weights(d0, P.conv0.weight, want_dgrad=False)
+    h0 = ops.conv_forward(d0, x, wf0, P.conv0.bias)
+    m0, i0 = _bn_forward(h0, P.bn0, training)
+    a0 = ops.bn_apply(h0, m0, i0, P.bn0.weight, P.bn0.bias, relu=True)
+    d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1)
+    wf3, wd3 = ops.pack_weights(d3, P.conv3.weight)
+    e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias)
+    r4, s4 = resblock_forward(e3, P.res4, training)
+    ze, s5 = resblock_forward(r4, P.res5, training)
+    saved = (x, h0, a0, m0, i0, d0, d3, wd3, s4, s5)
+    return ze, saved
+
+
+def encoder_backward(dze, saved, P: EncoderParams, gout=None):
+    """Gradients of every encoder parameter, in state_dict order (input gets none: it is data).
+    gout: optional list of 22 preallocated tensors to write into."""
+    x, h0, a0, m0, i0, d0, d3, wd3, s4, s5 = saved
+    o = gout if gout is not None else [None] * 22
+    dr4, g5 = resblock_backward(dze, s5, P.res5, gout=o[14:22] if gout is not None else None)
+    de3, g4 = resblock_backward(dr4, s4, P.res4, gout=o[6:14] if gout is not None else None)
+    dw3, db3 = ops.conv_wgrad(d3, a0, de3, P.conv3.weight.shape, dw=o[4], dbias=o[5])
+    da0 = ops.conv_dgrad(d3, de3, wd3)
+    dh0, dg0, dbe0 = ops.bn_backward(h0, a0, da0, m0, i0, P.bn0.weight, dgamma=o[2], dbeta=o[3])
+    dw0, db0 = ops.conv_wgrad(d0, x, dh0, P.conv0.weight.shape, dw=o[0], dbias=o[1])
+    return [dw0, db0, dg0, dbe0, dw3, db3] + g4 + g5
+
+
+# ------------------------------------------------------------------------------------------------
+# Decoder   (src/models.py:175-184)
+# ------------------------------------------------------------------------------------------------
+def decoder_forward(zq, P: DecoderParams, training: bool):
+    """zq NHWC (B, h, w, D) -> x_tilde NHWC (B, 4h, 4w, 1)."""
+    B, H, W, D = zq.shape
+    r0, s0 = resblock_forward(zq, P.res0, training)
+    r1, s1 = resblock_forward(r0, P.res1, training)
+    dT = ops.conv_desc(B, H, W, D, D, 4, 2, 1, transposed=True)
+    wfT, wdT = ops.pack_weights(dT, P.convt3.weight)
+    u = ops.conv_forward(dT, r1, wfT, P.convt3.bias, flags=NSG_RELU_IN)   # decoder.2 ReLU fused into the load
+    m, i = _bn_forward(u, P.bn4, training)
+    a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
+    d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True)
+    wf6, wd6 = ops.pack_weights(d6, P.convt6.weight)
+    xt = ops.conv_forward(d6, a, wf6, P.convt6.bias, flags=NSG_TANH_OUT)  # decoder.7 Tanh fused into the epilogue
+    saved = (r1, u, a, m, i, xt, dT, d6, wdT, wd6, s0, s1)
+    return xt, saved
+
+
+def decoder_backward(dxt, saved, P: DecoderParams, need_dz: bool = True, dxt_is_pre_tanh: bool = False, gout=None):
+    """dxt: gradient w.r.t. x_tilde (or w.r.t. the tanh input when dxt_is_pre_tanh).
+    Returns (dzq, grads in state_dict order).  gout: optional list of 22 preallocated tensors."""
+    r1, u, a, m, i, xt, dT, d6, wdT, wd6, s0, s1 = saved
+    o = gout if gout is not None else [None] * 22
+    dpre = dxt if dxt_is_pre_tanh else ops.tanh_backward(dxt, xt)
+    dw6, db6 = ops.conv_wgrad(d6, a, dpre, P.convt6.weight.shape, dw=o[20], dbias=o[21])
+    da = ops.conv_dgrad(d6, dpre, wd6)
+    du, dg4, dbe4 = ops.bn_backward(u, a, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19])
+    dwT, dbT = ops.conv_wgrad(dT, r1, du, P.convt3.weight.shape, flags=NSG_RELU_IN, dw=o[16], dbias=o[17])
+    dr1_pre = ops.conv_dgrad(dT, du, wdT)
+    dr1 = ops.relu_backward_add(dr1_pre, None, r1)
+    dr0, g1 = resblock_backward(dr1, s1, P.res1, gout=o[8:16] if gout is not None else None)
+    dzq, g0 = resblock_backward(dr0, s0, P.res0, need_dx=need_dz, gout=o[0:8] if gout is not None else None)
+    return dzq, g0 + g1 + [dwT, dbT, dg4, dbe4, dw6, db6]
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers to pull parameter bundles out of the nn.Module tree (names follow the reference)
+# ------------------------------------------------------------------------------------------------
+def conv_params(m) -> ConvParams:
+    return ConvParams(m.weight, m.bias)
+
+
+def bn_params(m) -> BNParams:
+    return BNParams(m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked)
+
+
+def resblock_params(rb) -> ResBlockParams:
+    return ResBlockParams(conv_params(rb.block[1]), bn_params(rb.block[2]), conv_params(rb.block[4]), bn_params(rb.block[5]))
+
+
+def encoder_params(enc) -> EncoderParams:
+    return EncoderParams(conv_params(enc[0]), bn_params(enc[1]), conv_params(enc[3]), resblock_params(enc[4]),
+                         resblock_params(enc[5]))
+
+
+def decoder_params(dec) -> DecoderParams:
+    return DecoderParams(resblock_params(dec[0]), resblock_params(dec[1]), conv_params(dec[3]), bn_params(dec[4]),
+                         conv_params(dec[6]))
+
+
+def resblock_param_list(P: ResBlockParams) -> List[torch.Tensor]:
+    return [P.conv1.weight, P.conv1.bias, P.bn1.weight, P.bn1.bias, P.conv2.weight, P.conv2.bias, P.bn2.weight, P.bn2.bias]
+
+
+def encoder_param_list(P: EncoderParams) -> List[torch.Tensor]:
+    return [P.conv0.weight, P.conv0.bias, P.bn0.weight, P.bn0.bias, P.conv3.weight, P.conv3.bias] + \
+        resblock_param_list(P.res4) + resblock_param_list(P.res5)
+
+
+def decoder_param_list(P: DecoderParams) -> List[torch.Tensor]:
+    return resblock_param_list(P.res0) + resblock_param_list(P.res1) + \
+        [P.convt3.weight, P.convt3.bias, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias]

@@ -1,0 +1,96 @@
+"""torch.autograd.Function wrappers around the engine's explicit forward/backward pieces, so the
+fused encoder / decoder / ResBlock stacks compose with ordinary autograd code (the reference's
+src/train.py calls loss.backward() on the model outputs).
+
+Tensors cross this boundary in the reference's logical NCHW shape; physically they are NHWC
+("channels_last"), so the permutes below are views, not copies.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import engine
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) logical -> contiguous [B][H][W][C]; free when x is channels_last or C == 1."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw_view(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)
+
+
+def _check_float_cuda(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(f"{what}: this path runs only on an AMD GPU (got a {x.device} tensor); there is no CPU fallback")
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{what}: expected float32, got {x.dtype}")
+
+
+class _Stack(Function):
+    """Shared plumbing: subclasses set fwd / bwd / bundle."""
+
+    @staticmethod
+    def _run_forward(ctx, fwd, bundle, x, training, params):
+        _check_float_cuda(x, fwd.__name__)
+        ctx.bundle = bundle
+        ctx.training = training
+        y, saved = fwd(to_nhwc(x.detach()), bundle, training)
+        ctx.saved = saved
+        return to_nchw_view(y)
+
+
+class EncoderFn(Function):
+    @staticmethod
+    def forward(ctx, x, bundle, training, *params):
+        return _Stack._run_forward(ctx, engine.encoder_forward, bundle, x, training, params)
+
+    @staticmethod
+    def backward(ctx, dz):
+        if not ctx.training:
+            raise RuntimeError("backward through the encoder in eval() mode is not implemented")
+        grads = engine.encoder_backward(to_nhwc(dz), ctx.saved, ctx.bundle)
+        ctx.saved = None
+        return (None, None, None) + tuple(grads)
+
+
+class DecoderFn(Function):
+    @staticmethod
+    def forward(ctx, z, bundle, training, *params):
+        return _Stack._run_forward(ctx, engine.decoder_forward, bundle, z, training, params)
+
+    @staticmethod
+    def backward(ctx, dxt):
+        if not ctx.training:
+            raise RuntimeError("backward through the decoder in eval() mode is not implemented")
+        dz, grads = engine.decoder_backward(to_nhwc(dxt), ctx.saved, ctx.bundle, need_dz=ctx.needs_input_grad[0])
+        ctx.saved = None
+        return (to_nchw_view(dz) if dz is not None else None, None, None) + tuple(grads)
+
+
+class ResBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, bundle, training, *params):
+        return _Stack._run_forward(ctx, engine.resblock_forward, bundle, x, training, params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("backward through a ResBlock in eval() mode is not implemented")
+        dx, grads = engine.resblock_backward(to_nhwc(dy), ctx.saved, ctx.bundle, need_dx=ctx.needs_input_grad[0])
+        ctx.saved = None
+        return (to_nchw_view(dx) if dx is not None else None, None, None) + tuple(grads)
+
+
+def encoder_apply(x, bundle, training):
+    return EncoderFn.apply(x, bundle, training, *engine.encoder_param_list(bundle))
+
+
+def decoder_apply(z, bundle, training):
+    return DecoderFn.apply(z, bundle, training, *engine.decoder_param_list(bundle))
+
+
+def resblock_apply(x, bundle, training):
+    return ResBlockFn.apply(x, bundle, training, *engine.resblock_param_list(bundle))

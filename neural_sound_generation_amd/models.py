@@ -1,0 +1,135 @@
+"""nn.Module surface of the reference's src/models.py (VQ-VAE part), backed by libnsg.so.
+
+    VQVAE(input_dim, dim, z_dim=512)   .encoder .codebook .decoder
+        .forward(x) -> (x_tilde, z_e_x, z_q_x)      models.py:198-216
+        .encode(x)  -> int64 latents                 models.py:188-191
+        .decode(latents) -> x_tilde                  models.py:193-196
+    VQEmbedding(z_dim, dim)            .embedding (nn.Embedding), .forward, .straight_through   :121-142
+    ResBlock(dim)                      .block (nn.Sequential)                                    :145-158
+    weights_init(m)                                                                              :25-32
+
+Constructor signatures, attribute names, state_dict keys/shapes and the RNG consumption order of
+construction are the reference's, so checkpoints interchange both ways and `torch.manual_seed(s);
+VQVAE(...)` gives the same initial weights.  The child modules are the stock parameter containers
+(nn.Conv2d, nn.BatchNorm2d, ...); the stacks that own them override forward() to run the fused HIP
+engine (engine.py), so no vendor convolution library is ever called.  There is no CPU fallback:
+calling a module on a CPU tensor raises.
+
+Input is the reference's (B, 1, 80, T) float32 mel batch.  Outputs have the reference's logical
+NCHW shapes; z_e_x / z_q_x are channels_last in memory.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import engine, functional as Fn, ops
+from .vector_quantization import vq, vq_st, codebook_lookup
+
+
+def to_scalar(arr):
+    if type(arr) == list:
+        return [x.item() for x in arr]
+    return arr.item()
+
+
+def weights_init(m):
+    """Xavier-uniform weights and zero bias on every module whose class name contains 'Conv'
+    (models.py:25-32).  Works on the fused stacks too: apply() visits their child containers."""
+    classname = m.__class__.__name__
+    if classname.find('Conv') != -1:
+        try:
+            nn.init.xavier_uniform_(m.weight.data)
+            m.bias.data.fill_(0)
+        except AttributeError:
+            print("Skipping initialization of ", classname)
+
+
+class VQEmbedding(nn.Module):
+    def __init__(self, z_dim, dim):
+        super().__init__()
+        self.embedding = nn.Embedding(z_dim, dim)
+        self.embedding.weight.data.uniform_(-1. / z_dim, 1. / z_dim)
+
+    def forward(self, z_e_x):
+        z_e_x_ = Fn.to_nhwc(z_e_x)
+        return vq(z_e_x_, self.embedding.weight)
+
+    def straight_through(self, z_e_x):
+        z_e_x_ = Fn.to_nhwc(z_e_x)
+        z_q_x_, indices = vq_st(z_e_x_, self.embedding.weight.detach())
+        z_q_x = Fn.to_nchw_view(z_q_x_)
+        z_q_x_bar_ = codebook_lookup(self.embedding.weight, indices).view_as(z_e_x_)
+        z_q_x_bar = Fn.to_nchw_view(z_q_x_bar_)
+        return z_q_x, z_q_x_bar
+
+
+class ResBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.ReLU(True),
+            nn.Conv2d(dim, dim, 3, 1, 1),
+            nn.BatchNorm2d(dim),
+            nn.ReLU(True),
+            nn.Conv2d(dim, dim, 1),
+            nn.BatchNorm2d(dim)
+        )
+
+    def forward(self, x):
+        # y = relu(x) + block(relu(x)).  The reference also overwrites its argument with relu(x)
+        # (nn.ReLU(True), models.py:149); inside VQVAE nothing reads that tensor again, and the
+        # fused kernels never mutate their inputs.
+        return Fn.resblock_apply(x, engine.resblock_params(self), self.training)
+
+
+class _Encoder(nn.Sequential):
+    def forward(self, x):
+        return Fn.encoder_apply(x, engine.encoder_params(self), self.training)
+
+
+class _Decoder(nn.Sequential):
+    def forward(self, z):
+        return Fn.decoder_apply(z, engine.decoder_params(self), self.training)
+
+
+class VQVAE(nn.Module):
+    def __init__(self, input_dim, dim, z_dim=512):
+        super().__init__()
+        if input_dim != 1:
+            raise NotImplementedError("the HIP path implements the speech configuration (input_dim == 1: "
+                                      "one-channel 80-bin mel images, src/train.py:115)")
+        self.encoder = _Encoder(
+            nn.Conv2d(input_dim, dim, 4, 2, 1),
+            nn.BatchNorm2d(dim),
+            nn.ReLU(True),
+            nn.Conv2d(dim, dim, 4, 2, 1),
+            ResBlock(dim),
+            ResBlock(dim),
+        )
+        self.codebook = VQEmbedding(z_dim, dim)
+        self.decoder = _Decoder(
+            ResBlock(dim),
+            ResBlock(dim),
+            nn.ReLU(True),
+            nn.ConvTranspose2d(dim, dim, 4, 2, 1),
+            nn.BatchNorm2d(dim),
+            nn.ReLU(True),
+            nn.ConvTranspose2d(dim, input_dim, 4, 2, 1),
+            nn.Tanh()
+        )
+        self.apply(weights_init)
+
+    def encode(self, x):
+        z_e_x = self.encoder(x)
+        return self.codebook(z_e_x)
+
+    def decode(self, latents):
+        z_q_x = Fn.to_nchw_view(ops.gather_rows(self.codebook.embedding.weight.detach().contiguous(), latents.contiguous()))
+        return self.decoder(z_q_x)
+
+    def forward(self, x):
+        z_e_x = self.encoder(x)
+        z_q_x_st, z_q_x = self.codebook.straight_through(z_e_x)
+        x_tilde = self.decoder(z_q_x_st)
+        return x_tilde, z_e_x, z_q_x

@@ -1,0 +1,274 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs/workspaces as torch tensors
+(so the caching allocator and stream semantics apply), pass raw pointers + the current HIP stream.
+PyTorch is plumbing here: device memory, streams, autograd glue -- all arithmetic is in libnsg.so.
+All activations are fp32 NHWC; see include/nsg.h.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, NSG_RELU_IN, NSG_TANH_OUT  # noqa: F401
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.NsgError(f"{name}: expected a GPU tensor (this path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.NsgError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.NsgError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+class Workspace:
+    """One growing scratch buffer per device; kernels on one stream run in order, so reuse is safe."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+WS = Workspace()
+
+
+# ------------------------------------------------------------------------------------------------
+# vector quantiser
+# ------------------------------------------------------------------------------------------------
+def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma"):
+    """x2d (N,D), codebook (K,D) -> idx (N,) int64 [, codes (N,D)] [, dmin (N,)]"""
+    _chk(x2d, "x"); _chk(codebook, "codebook")
+    N, D = x2d.shape
+    K, D2 = codebook.shape
+    if D != D2:
+        raise _lib.NsgError(f"vq_forward: input rows have {D} columns, codebook has {D2}")
+    idx = torch.empty(N, dtype=torch.int64, device=x2d.device)
+    codes = torch.empty_like(x2d) if want_codes else None
+    dmin = torch.empty(N, dtype=torch.float32, device=x2d.device) if want_dist else None
+    if N > 0:
+        nb = _lib.query("nsg_vq_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
+        ws = WS.get(nb, x2d.device)
+        fn = "nsg_vq_forward" if impl == "mfma" else "nsg_debug_vq_forward_valu"
+        _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin),
+                  _p(ws), c_size_t(nb), _stream())
+    return idx, codes, dmin
+
+
+def rowsumsq(v):
+    _chk(v, "v")
+    out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+    _lib.call("nsg_rowsumsq", _p(v), c_int64(v.shape[0]), c_int32(v.shape[1]), _p(out), _stream())
+    return out
+
+
+def index_add_rows(idx, g2d, K, want_counts=False):
+    """out[k] = sum of rows of g2d whose idx == k; deterministic."""
+    _chk(idx, "idx", torch.int64); _chk(g2d, "g")
+    N, D = g2d.shape
+    out = torch.empty(K, D, dtype=torch.float32, device=g2d.device)
+    counts = torch.empty(K, dtype=torch.float32, device=g2d.device) if want_counts else None
+    nb = _lib.query("nsg_index_add_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
+    ws = WS.get(nb, g2d.device)
+    _lib.call("nsg_index_add_rows", _p(idx), _p(g2d), c_int64(N), c_int32(D), c_int32(K), _p(out), _p(counts), _p(ws),
+              c_size_t(nb), _stream())
+    return (out, counts) if want_counts else out
+
+
+def gather_rows(codebook, idx):
+    """codebook (K,D), idx (...) int64 -> (..., D)"""
+    _chk(codebook, "codebook"); _chk(idx, "idx", torch.int64)
+    K, D = codebook.shape
+    out = torch.empty(*idx.shape, D, dtype=torch.float32, device=codebook.device)
+    _lib.call("nsg_gather_rows", _p(codebook), _p(idx), c_int64(idx.numel()), c_int32(D), c_int32(K), _p(out), _stream())
+    return out
+
+
+def vq_ema_update(codebook, ema_n, ema_s, n, s, decay=0.99, eps=1e-5):
+    K, D = codebook.shape
+    scratch = torch.empty(1, dtype=torch.float32, device=codebook.device)
+    _lib.call("nsg_vq_ema_update", _p(codebook), _p(ema_n), _p(ema_s), _p(n), _p(s), c_int32(K), c_int32(D),
+              c_float(decay), c_float(eps), _p(scratch), _stream())
+
+
+def debug_dot(x, e, mode):
+    out = torch.empty(x.shape[0], e.shape[0], dtype=torch.float32, device=x.device)
+    _lib.call("nsg_debug_dot", _p(x), _p(e), c_int32(x.shape[0]), c_int32(x.shape[1]), c_int32(e.shape[0]), c_int32(mode),
+              _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions
+# ------------------------------------------------------------------------------------------------
+def conv_desc(B, IH, IW, C_in, C_out, k, stride, pad, transposed=False) -> ConvDesc:
+    if transposed:
+        OH, OW = (IH - 1) * stride - 2 * pad + k, (IW - 1) * stride - 2 * pad + k
+    else:
+        OH, OW = (IH + 2 * pad - k) // stride + 1, (IW + 2 * pad - k) // stride + 1
+    return ConvDesc(B, IH, IW, C_in, OH, OW, C_out, k, stride, pad, 1 if transposed else 0)
+
+
+def pack_weights(d: ConvDesc, w, want_fwd=True, want_dgrad=True):
+    _chk(w, "weight")
+    n = _lib.query("nsg_packed_weight_floats", byref(d))
+    wf = torch.empty(n, dtype=torch.float32, device=w.device) if want_fwd else None
+    wd = torch.empty(n, dtype=torch.float32, device=w.device) if want_dgrad else None
+    _lib.call("nsg_pack_conv_weights", byref(d), _p(w), _p(wf), _p(wd), _stream())
+    return wf, wd
+
+
+def _conv_ws(d, device):
+    nb = _lib.query("nsg_conv_workspace_bytes", byref(d))
+    return WS.get(nb, device), nb
+
+
+def conv_forward(d: ConvDesc, x, w_fwd, bias, flags=0, out=None):
+    """x NHWC (B,IH,IW,C_in) -> y NHWC (B,OH,OW,C_out)."""
+    _chk(x, "x")
+    if tuple(x.shape) != (d.B, d.IH, d.IW, d.C_in):
+        raise _lib.NsgError(f"conv_forward: input shape {tuple(x.shape)} does not match descriptor {d.key()}")
+    y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=torch.float32, device=x.device)
+    ws, nb = _conv_ws(d, x.device)
+    _lib.call("nsg_conv_forward", byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), c_int32(flags), _p(ws), c_size_t(nb), _stream())
+    return y
+
+
+def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
+    _chk(dy, "dy")
+    if tuple(dy.shape) != (d.B, d.OH, d.OW, d.C_out):
+        raise _lib.NsgError(f"conv_dgrad: dy shape {tuple(dy.shape)} does not match descriptor {d.key()}")
+    dx = out if out is not None else torch.empty(d.B, d.IH, d.IW, d.C_in, dtype=torch.float32, device=dy.device)
+    ws, nb = _conv_ws(d, dy.device)
+    _lib.call("nsg_conv_dgrad", byref(d), _p(dy), _p(w_dgrad), _p(dx), c_int32(0), _p(ws), c_size_t(nb), _stream())
+    return dx
+
+
+def conv_wgrad(d: ConvDesc, x, dy, w_shape, flags=0, dw=None, dbias=None, want_bias=True):
+    _chk(x, "x"); _chk(dy, "dy")
+    if dw is None:
+        dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty(d.C_out, dtype=torch.float32, device=x.device)
+    ws, nb = _conv_ws(d, x.device)
+    _lib.call("nsg_conv_wgrad", byref(d), _p(x), _p(dy), _p(dw), _p(dbias), c_int32(flags), _p(ws), c_size_t(nb), _stream())
+    return dw, dbias
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm over [M][C]
+# ------------------------------------------------------------------------------------------------
+def bn_stats(x, C, running_mean=None, running_var=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    _chk(x, "x")
+    M = x.numel() // C
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
+    ws = WS.get(nb, x.device)
+    _lib.call("nsg_bn_stats", _p(x), c_int64(M), c_int32(C), c_float(eps), c_float(momentum), _p(mean), _p(invstd),
+              _p(running_mean), _p(running_var), _p(ws), c_size_t(nb), _stream())
+    return mean, invstd
+
+
+def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
+    C = running_mean.numel()
+    mean = torch.empty(C, dtype=torch.float32, device=running_mean.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=running_mean.device)
+    _lib.call("nsg_bn_eval_stats", _p(running_mean), _p(running_var), c_int32(C), c_float(eps), _p(mean), _p(invstd), _stream())
+    return mean, invstd
+
+
+def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_residual=False, out=None):
+    _chk(x, "x")
+    C = mean.numel()
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    _lib.call("nsg_bn_apply", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), _p(y), c_int64(M), c_int32(C),
+              c_int32(1 if relu else 0), c_int32(1 if relu_residual else 0), _stream())
+    return y
+
+
+def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out=None):
+    _chk(x, "x"); _chk(dy, "dy")
+    C = mean.numel()
+    M = x.numel() // C
+    dx = out if out is not None else torch.empty_like(x)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
+    ws = WS.get(nb, x.device)
+    _lib.call("nsg_bn_backward", _p(x), _p(y_relu), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+              c_int64(M), c_int32(C), _p(ws), c_size_t(nb), _stream())
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# element-wise / losses / optimiser
+# ------------------------------------------------------------------------------------------------
+def relu_backward_add(a, b, x, out=None):
+    dx = out if out is not None else torch.empty_like(x)
+    _lib.call("nsg_relu_backward_add", _p(a), _p(b), _p(x), _p(dx), c_int64(x.numel()), _stream())
+    return dx
+
+
+def tanh_backward(g, y, out=None):
+    dx = out if out is not None else torch.empty_like(y)
+    _lib.call("nsg_tanh_backward", _p(g), _p(y), _p(dx), c_int64(y.numel()), _stream())
+    return dx
+
+
+def add(a, b, out=None):
+    y = out if out is not None else torch.empty_like(a)
+    _lib.call("nsg_add", _p(a), _p(b), _p(y), c_int64(a.numel()), _stream())
+    return y
+
+
+def mse_padded(a, c, rows, wa, wc, grad_scale=1.0, want_grad=True):
+    """mean((pad(a) - c)^2) with a zero-padded from width wa to wc (train.py:118-129)."""
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(rows * wc))
+    ws = WS.get(nb, a.device)
+    _lib.call("nsg_mse_padded", _p(a), _p(c), c_int64(rows), c_int32(wa), c_int32(wc), c_float(grad_scale), _p(loss), _p(da),
+              _p(ws), c_size_t(nb), _stream())
+    return loss, da
+
+
+def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_dq=True):
+    """mean((q - z)^2) and its two one-sided gradients (train.py:131,133)."""
+    n = z.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_dz else None
+    dq = torch.empty_like(z) if want_dq else None
+    nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(n))
+    ws = WS.get(nb, z.device)
+    _lib.call("nsg_vq_losses", _p(z), _p(q), c_int64(n), c_float(dz_scale), c_float(dq_scale), _p(dz_add), _p(loss), _p(dz),
+              _p(dq), _p(ws), c_size_t(nb), _stream())
+    return loss, dz, dq
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _lib.call("nsg_adam_step", _p(p), _p(g), _p(m), _p(v), c_int64(p.numel()), c_float(lr), c_float(beta1), c_float(beta2),
+              c_float(eps), c_int32(step), c_float(grad_scale), _stream())

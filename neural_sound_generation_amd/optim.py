@@ -1,0 +1,69 @@
+"""Flat-bucket Adam: every parameter of the model lives in ONE contiguous fp32 buffer (each tensor
+256-byte aligned inside it), gradients in a second one, so the optimiser is a single kernel launch
+(nsg_adam_step) and data-parallel training needs a single all-reduce per step.
+
+Arithmetic = torch.optim.Adam defaults as constructed at src/main.py:124 (no weight decay, no
+amsgrad), applied element-wise, so the update is identical to the per-tensor optimiser's.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+_ALIGN = 64  # floats (256 bytes): keeps every view 16-byte aligned for the float4 kernels
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._params = [p for g in self.param_groups for p in g["params"]]
+        if not self._params:
+            raise ValueError("FlatAdam got no parameters")
+        dev = self._params[0].device
+        offs, total = [], 0
+        for p in self._params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("FlatAdam needs float32 parameters on one device")
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.offsets, self.total = offs, total
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad_views = []
+        with torch.no_grad():
+            for p, off in zip(self._params, offs):
+                view = self.flat_param[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view                      # parameters now alias the flat buffer
+                gview = self.flat_grad[off:off + p.numel()].view_as(p)
+                p.grad = gview                     # autograd accumulates in place into the bucket
+                self.grad_views.append(gview)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        # the views must survive: never set to None
+        self.flat_grad.zero_()
+        for p, g in zip(self._params, self.grad_views):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def grads_for(self, tensors):
+        """Bucket views for the given parameter tensors (same order)."""
+        index = {id(p): i for i, p in enumerate(self._params)}
+        return [self.grad_views[index[id(t)]] for t in tensors]
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self.step_count += 1
+        if self.flat_param.is_cuda:
+            ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=g["lr"],
+                          beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], grad_scale=grad_scale)
+        else:
+            raise RuntimeError("FlatAdam.step: parameters are not on a GPU; this path has no CPU fallback")
+        return loss

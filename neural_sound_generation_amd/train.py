@@ -1,0 +1,111 @@
+"""The reference's per-batch training step (src/train.py:104-148, ljspeech branch) on the HIP path.
+
+Two ways to run it:
+
+  * `train_vqvae(args, model, optimizer, train_loader, device, epoch)` -- same signature and
+    behaviour as the reference's function: autograd through the model's fused stacks, three
+    F.mse_loss terms, optimizer.step().  Any torch optimizer works (FlatAdam is the fused one).
+
+  * `FusedTrainStep` -- the same arithmetic with no autograd in the loop: forward, the three loss
+    terms and their gradients from two fused kernels, explicit backward writing straight into the
+    flat gradient bucket, one all-reduce when data-parallel, one Adam kernel.  This is what bench.py
+    times.  The zero-pad-to-input-width of train.py:118-120 is folded into the loss kernel (the
+    reference bounces through host memory there).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import distributed as nsg_dist
+from . import engine, functional as Fn, ops
+from .optim import FlatAdam
+
+
+class FusedTrainStep:
+    def __init__(self, model, lr: float = 1e-3, beta: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None, optimizer: FlatAdam | None = None):
+        self.model = model
+        self.beta = float(beta)
+        self.group = process_group
+        self.opt = optimizer if optimizer is not None else FlatAdam(model.parameters(), lr=lr, betas=betas, eps=eps)
+        self.world = nsg_dist.world_size(process_group)
+        if self.world > 1:
+            nsg_dist.broadcast_flat(self.opt.flat_param, 0, process_group)
+        self.encP = engine.encoder_params(model.encoder)
+        self.decP = engine.decoder_params(model.decoder)
+        self.codebook = model.codebook.embedding.weight
+        self.g_enc = self.opt.grads_for(engine.encoder_param_list(self.encP))
+        self.g_dec = self.opt.grads_for(engine.decoder_param_list(self.decP))
+        self.g_code = self.opt.grads_for([self.codebook])[0]
+
+    @torch.no_grad()
+    def forward_backward(self, c: torch.Tensor):
+        """c: (B,1,80,T) float32 on the GPU.  Fills the flat gradient bucket; returns the three loss
+        tensors (device scalars; nothing here synchronises with the host)."""
+        model = self.model
+        if not model.training:
+            raise RuntimeError("FusedTrainStep needs model.train()")
+        x = Fn.to_nhwc(c)
+        B, H, T, _ = x.shape
+        ze, es = engine.encoder_forward(x, self.encP, True)
+        D = ze.shape[-1]
+        K = self.codebook.shape[0]
+        idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True)
+        zq = zq.view_as(ze)
+        xt, ds = engine.decoder_forward(zq, self.decP, True)
+        # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
+        loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
+        dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)
+        # loss_vq = mse(z_q, sg(z_e)) -> codebook; loss_commit = mse(z_e, sg(z_q)) -> encoder,
+        # plus the straight-through gradient from the decoder               (train.py:131-134)
+        loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq)
+        self._codebook_grad(idx, dq.view(-1, D), K)
+        engine.encoder_backward(dz, es, self.encP, gout=self.g_enc)
+        self.last_indices = idx
+        return loss_recons, loss_vq, loss_vq
+
+    def _codebook_grad(self, idx, dq, K):
+        g = ops.index_add_rows(idx, dq, K)
+        ops.add(g, None, out=self.g_code)
+
+    @torch.no_grad()
+    def step(self, c: torch.Tensor):
+        losses = self.forward_backward(c)
+        if self.world > 1:
+            nsg_dist.allreduce_sum_(self.opt.flat_grad, self.group)
+        self.opt.step(grad_scale=1.0 / self.world)
+        return losses
+
+
+def vqvae_loss_terms(c, x_tilde, z_e_x, z_q_x):
+    """train.py:118-133 on device tensors (autograd path): zero-pad without the host round trip."""
+    if x_tilde.size(3) != c.size(3):
+        target = F.pad(x_tilde, (0, c.size(3) - x_tilde.size(3)))
+    else:
+        target = x_tilde
+    loss_recons = F.mse_loss(target, c)
+    loss_vq = F.mse_loss(z_q_x, z_e_x.detach())
+    loss_commit = F.mse_loss(z_e_x, z_q_x.detach())
+    return loss_recons, loss_vq, loss_commit
+
+
+def train_vqvae(args, model, optimizer, train_loader, device, epoch):
+    """Drop-in for the reference's train_vqvae (src/train.py:104-148, ljspeech branch).
+    `train_loader` yields (x, y, c, g, input_lengths) with c: (B, 80, T) mel frames."""
+    model.train()
+    train_loss = 0
+    n_batches = 0
+    for batch_idx, (x, y, c, g, input_lengths) in enumerate(train_loader):
+        optimizer.zero_grad()
+        c = c.to(device).unsqueeze(1)
+        x_tilde, z_e_x, z_q_x = model(c)
+        loss_recons, loss_vq, loss_commit = vqvae_loss_terms(c, x_tilde, z_e_x, z_q_x)
+        loss = loss_recons + loss_vq + args.beta * loss_commit
+        loss.backward()
+        optimizer.step()
+        train_loss = loss_recons.item() + loss_vq.item()
+        n_batches += 1
+        if batch_idx % args.log_interval == 0:
+            print('Train Epoch: {} [{}/{}]\tLoss: {:.6f}'.format(epoch, batch_idx * len(c), len(train_loader.dataset), train_loss))
+    return train_loss

@@ -1,0 +1,83 @@
+"""Operator surface of the reference's src/vector_quantization.py, on hand-written HIP kernels.
+
+    vq(inputs[..., D], codebook[K, D])     -> int64 indices[...]           (not differentiable)
+    vq_st(inputs[..., D], codebook[K, D])  -> (codes like inputs, indices_flat[N])   straight-through
+
+Same names, argument meaning and error behaviour as the reference (vector_quantization.py:4-66):
+differentiating through plain `vq` raises RuntimeError (:26-30); `vq_st` passes the output gradient
+straight to the inputs (:52) and scatter-adds it into the codebook gradient when the codebook
+requires grad (:53-61).  The search itself is nsg_vq_forward: distances are never materialised and
+the indices are bit-identical to the reference's CPU result.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class VectorQuantization(Function):
+    @staticmethod
+    def forward(ctx, inputs, codebook):
+        with torch.no_grad():
+            embedding_size = codebook.size(1)
+            flat = inputs.detach().contiguous().view(-1, embedding_size)
+            idx, _, _ = ops.vq_forward(flat, codebook.detach().contiguous(), want_codes=False)
+            indices = idx.view(*inputs.shape[:-1])
+            ctx.mark_non_differentiable(indices)
+            return indices
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise RuntimeError('Trying to call `.grad()` on graph containing `VectorQuantization`. '
+                           'The function `VectorQuantization` is not differentiable. '
+                           'Use `VectorQuantizationStraightThrough` if you want a straight-through '
+                           'estimator of the gradient.')
+
+
+class VectorQuantizationStraightThrough(Function):
+    @staticmethod
+    def forward(ctx, inputs, codebook):
+        embedding_size = codebook.size(1)
+        flat = inputs.detach().contiguous().view(-1, embedding_size)
+        cb = codebook.detach().contiguous()
+        indices_flatten, codes_flatten, _ = ops.vq_forward(flat, cb, want_codes=True)  # search + gather fused
+        ctx.save_for_backward(indices_flatten)
+        ctx.codebook_rows = cb.size(0)
+        ctx.mark_non_differentiable(indices_flatten)
+        return codes_flatten.view_as(inputs), indices_flatten
+
+    @staticmethod
+    def backward(ctx, grad_output, grad_indices):
+        grad_inputs, grad_codebook = None, None
+        if ctx.needs_input_grad[0]:
+            grad_inputs = ops.add(grad_output.contiguous(), None)  # straight-through estimator (a copy)
+        if ctx.needs_input_grad[1]:
+            (indices,) = ctx.saved_tensors
+            g = grad_output.contiguous().view(indices.numel(), -1)
+            grad_codebook = ops.index_add_rows(indices, g, ctx.codebook_rows)
+        return grad_inputs, grad_codebook
+
+
+class CodebookLookup(Function):
+    """codebook[indices] with gradient to the codebook: the reference's
+    torch.index_select(self.embedding.weight, 0, indices) (src/models.py:137-138)."""
+
+    @staticmethod
+    def forward(ctx, codebook, indices):
+        ctx.save_for_backward(indices)
+        ctx.codebook_rows = codebook.size(0)
+        return ops.gather_rows(codebook.detach().contiguous(), indices)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (indices,) = ctx.saved_tensors
+        g = grad_output.contiguous().view(indices.numel(), -1)
+        return ops.index_add_rows(indices.view(-1), g, ctx.codebook_rows), None
+
+
+vq = VectorQuantization.apply
+vq_st = VectorQuantizationStraightThrough.apply
+codebook_lookup = CodebookLookup.apply
+__all__ = ["vq", "vq_st", "codebook_lookup"]
