@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Benchmark of the VQ-VAE training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (forward, three losses, backward, [all-reduce], Adam) of
+VQVAE(1, D=128, K=512) (BASELINE.json configs[1], the reference's `--dim 128 --z-dim 512`) on a
+synthetic batch of B clips of 80-mel x 1024 frames per GPU, inputs resident in HBM before the timed
+region.  Weak scaling: B per GPU is fixed, rank r draws its own clips.  Prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def flops_per_frame(D: int, K: int) -> float:
+    """fwd+bwd FLOP per mel frame."""
+    return 2160.0 * D * D + 3200.0 * D + 10.0 * K * D
+
+
+def host_threads() -> int:
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU box's
+    documented per-GPU share (16) -- os.cpu_count() reports every core of the host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("NSG_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(D, K, T, threads, batch=4, warmup=1, steps=3):
+    """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on the host
+    cores: a bounded sample (batch clips x `steps` steps) of the same workload."""
+    from oracle import vqvae_oracle as O
+    from neural_sound_generation_amd import models as M
+    torch.set_num_threads(threads)
+    torch.manual_seed(1)
+    st = O.clone_state(M.VQVAE(1, D, K).state_dict())
+    opt = O.adam_init(st)
+    c = torch.rand(batch, 1, 80, T, generator=torch.Generator().manual_seed(1234))
+    for _ in range(warmup):
+        O.train_step(st, opt, c)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(st, opt, c)
+    dt = (time.perf_counter() - t0) / steps
+    return batch * T / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--z-dim", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from neural_sound_generation_amd import distributed as nsg_dist, models as M, ops
+    from neural_sound_generation_amd.train import FusedTrainStep
+
+    rank, world, local = nsg_dist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    D, K, T, B = args.dim, args.z_dim, args.frames, args.batch
+
+    torch.manual_seed(1)                       # src/main.py:43,71 -- identical init on every rank
+    model = M.VQVAE(1, D, K).to(dev).train()
+    step = FusedTrainStep(model, lr=1e-3, beta=1.0)
+    c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.step(c)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer()
+        ops.KERNEL_TIMER = timer
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step.step(c)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = world * B * T * args.steps
+    value = frames_total / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    loss_triple = [float(x.item()) for x in losses]
+
+    if rank == 0:
+        roof = None
+        if timer is not None:
+            s = timer.summary().get("gather_gemm_f32")
+            if s:
+                roof = {"bound": "mfma", "kernel": "gather_gemm_f32", "achieved": round(s["tflops"], 2),
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(s["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": None, "launches": s["launches"], "avg_launch_ms": round(s["avg_ms"], 4),
+                        "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
+                        "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            threads = host_threads()
+            v, dt = cpu_baseline(D, K, T, threads)
+            cpu = {"value": round(v, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
+                   "sample": f"oracle/vqvae_oracle.py train_step, 4 clips x 80x{T}, 1 warm-up + 3 timed steps ({dt * 1e3:.0f} ms/step)"}
+        line = {
+            "metric": "mel-frames/sec VQ-VAE fwd+bwd+Adam (80-mel x 1024)", "value": round(value, 1), "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: VQVAE(1, dim={D}, z_dim={K}), {B} clips/GPU of 80-mel x {T} frames, "
+                                   f"train step (fwd + 3 losses + bwd + Adam{' + grad all-reduce' if world > 1 else ''})",
+                       "clips_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
+                       "per_gpu_value": round(value / world, 1),
+                       "algorithmic_tflops": round(value * flops_per_frame(D, K) / 1e12, 2),
+                       "losses": loss_triple},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

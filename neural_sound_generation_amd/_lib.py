@@ -75,6 +75,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # Device memory and streams come from PyTorch-ROCm, so libnsg.so must bind to the HIP runtime
+    # torch carries (same SONAME as /opt/rocm's): load torch's first, or the process ends up with
+    # two HIP runtimes and the second one finds no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NsgError(
             f"{LIB_PATH} is missing: build the HIP kernels first (python -m neural_sound_generation_amd.build). "

@@ -53,6 +53,44 @@ class Workspace:
 WS = Workspace()
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the single-kernel GEMM launches (bench.py's roofline figure).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}   # name -> list of (start_event, end_event, flops)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, name, start, flops):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.setdefault(name, []).append((start, ev, flops))
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_ms, flops_per_launch, tflops)  (call after a synchronize)"""
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            fl = [f for _, _, f in recs]
+            tot_ms, tot_fl = sum(ms), float(sum(fl))
+            out[name] = dict(launches=len(recs), total_ms=tot_ms, avg_ms=tot_ms / len(recs),
+                             flops_per_launch=tot_fl / len(recs), tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0)
+        return out
+
+
+KERNEL_TIMER = None  # set to a KernelTimer() to time gather_gemm / wgrad launches
+
+
+def _gemm_flops(d: "ConvDesc") -> float:
+    """Algorithmic FLOPs of one forward / dgrad / wgrad of layer d: 2 * low-res pixels * k^2 * C_in * C_out."""
+    low = d.B * (d.IH * d.IW if d.transposed else d.OH * d.OW)
+    return 2.0 * low * d.k * d.k * d.C_in * d.C_out
+
+
 # ------------------------------------------------------------------------------------------------
 # vector quantiser
 # ------------------------------------------------------------------------------------------------
@@ -150,7 +188,11 @@ def conv_forward(d: ConvDesc, x, w_fwd, bias, flags=0, out=None):
         raise _lib.NsgError(f"conv_forward: input shape {tuple(x.shape)} does not match descriptor {d.key()}")
     y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=torch.float32, device=x.device)
     ws, nb = _conv_ws(d, x.device)
+    timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
+    t0 = KERNEL_TIMER.begin() if timed else None
     _lib.call("nsg_conv_forward", byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), c_int32(flags), _p(ws), c_size_t(nb), _stream())
+    if timed:
+        KERNEL_TIMER.end("gather_gemm_f32", t0, _gemm_flops(d))
     return y
 
 
@@ -160,7 +202,11 @@ def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
         raise _lib.NsgError(f"conv_dgrad: dy shape {tuple(dy.shape)} does not match descriptor {d.key()}")
     dx = out if out is not None else torch.empty(d.B, d.IH, d.IW, d.C_in, dtype=torch.float32, device=dy.device)
     ws, nb = _conv_ws(d, dy.device)
+    timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
+    t0 = KERNEL_TIMER.begin() if timed else None
     _lib.call("nsg_conv_dgrad", byref(d), _p(dy), _p(w_dgrad), _p(dx), c_int32(0), _p(ws), c_size_t(nb), _stream())
+    if timed:
+        KERNEL_TIMER.end("gather_gemm_f32", t0, _gemm_flops(d))
     return dx
 
 

@@ -38,6 +38,21 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-12)
 
 
+# A conv bias that feeds a BatchNorm has an exactly-zero gradient (BN subtracts the batch mean);
+# the reference and the HIP path both produce round-off noise there, so these are checked to BE
+# noise (tiny next to the same layer's weight gradient) instead of being compared element-wise.
+BIAS_BEFORE_BN = ("encoder.0.bias", "block.1.bias", "block.4.bias", "decoder.3.bias")
+
+
+def is_noise_bias(name):
+    return name.endswith(BIAS_BEFORE_BN)
+
+
+def assert_noise_bias(name, grad, named_grads):
+    wscale = float(np.abs(named_grads[name[:-len("bias")] + "weight"]).max())
+    assert float(np.abs(grad).max()) <= 1e-3 * wscale + 1e-6, f"{name}: gradient should be round-off noise"
+
+
 def index_flips_are_near_ties(idx_got, idx_ref, z_e_ref_nchw, codebook, tol=2e-6):
     """Rows where the index differs must be rows whose fp64 distances to the two codes differ by less
     than the noise a last-ulp change of z_e can cause."""
@@ -90,11 +105,15 @@ def test_tiny_model_autograd_step(golden_dir, si):
     idx = model.codebook(z_e.detach()).cpu().numpy()
     flips = index_flips_are_near_ties(idx, g[tag + "idx"], g[tag + "z_e"], g["sd0.codebook.embedding.weight"])
     assert flips <= max(1, idx.size // 500), f"{flips} index flips"
+    named = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
     if flips == 0:
-        for k, p in model.named_parameters():
+        for k, got in named.items():
+            if is_noise_bias(k):
+                assert_noise_bias(k, got, named)
+                continue
             want = g[tag + "grad." + k]
             scale = max(np.abs(want).max(), 1e-8)
-            err = np.abs(p.grad.cpu().numpy() - want).max()
+            err = np.abs(got - want).max()
             assert err <= 2e-4 * scale + 1e-8, f"grad {k}: err {err:.3e} scale {scale:.3e}"
     opt.step()
     sd = model.state_dict()
@@ -103,8 +122,10 @@ def test_tiny_model_autograd_step(golden_dir, si):
     assert int(sd["encoder.1.num_batches_tracked"]) == 1
     if flips == 0:
         for k, p in model.named_parameters():
+            if is_noise_bias(k):
+                continue  # Adam turns round-off-sized gradients into +-lr steps
             gk = np.abs(g[tag + "grad." + k])
-            big = gk > 1e-5  # Adam turns round-off-sized gradients into +-lr steps: compare where the gradient is real
+            big = gk > 1e-5
             np.testing.assert_allclose(p.detach().cpu().numpy()[big], g[tag + "sd1." + k][big], rtol=0, atol=5e-6, err_msg=k)
 
 
@@ -179,12 +200,18 @@ def test_tiny_data_parallel_identity(golden_dir):
     m = build(g).train()
     st = FusedTrainStep(m, lr=1e-3)
     st.opt.flat_grad.copy_(buckets[0] + buckets[1])   # what all_reduce(sum) leaves on every rank
-    for k, p in m.named_parameters():
+    named = {k: p.grad.cpu().numpy() * 0.5 for k, p in m.named_parameters()}
+    for k, got in named.items():
+        if is_noise_bias(k):
+            assert_noise_bias(k, got, named)
+            continue
         want = g["dp.grad." + k]
         scale = max(np.abs(want).max(), 1e-8)
-        assert np.abs(p.grad.cpu().numpy() * 0.5 - want).max() <= 2e-4 * scale + 1e-8, k
+        assert np.abs(got - want).max() <= 2e-4 * scale + 1e-8, k
     st.opt.step(grad_scale=0.5)
     for k, p in m.named_parameters():
+        if is_noise_bias(k):
+            continue
         big = np.abs(g["dp.grad." + k]) > 1e-5
         np.testing.assert_allclose(p.detach().cpu().numpy()[big], g["dp.sd1." + k][big], rtol=0, atol=5e-6, err_msg=k)
 
@@ -201,7 +228,11 @@ def test_cfg1_model_step(golden_dir):
     flips = int((step.last_indices.cpu().numpy() != g["s0.idx"].reshape(-1)).sum())
     assert flips <= max(1, g["s0.idx"].size // 500), f"{flips} index flips"
     if flips == 0:
+        named = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
         for k, p in model.named_parameters():
+            if is_noise_bias(k):
+                assert_noise_bias(k, named[k], named)
+                continue
             want = float(g["s0.gnorm." + k])
             got = p.grad.double().norm().item()
             assert abs(got - want) <= 2e-4 * want + 1e-7, f"{k}: {got} vs {want}"
@@ -214,7 +245,7 @@ def test_full_width_step_against_oracle(dim, z_dim, B, T):
     model = M.VQVAE(1, dim, z_dim)
     st0 = O.clone_state(model.state_dict())
     c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234))
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     rec = O.forward_backward(st0, c)
     model = model.to(DEV).train()
     step = FusedTrainStep(model, lr=1e-3)
@@ -233,7 +264,7 @@ def test_full_width_step_against_oracle(dim, z_dim, B, T):
     assert torch.equal(g1, step2.opt.flat_grad), "the training step must be bitwise reproducible"
     gn = {k: v.double().norm().item() for k, v in rec["grads"].items()}
     for k, p in model.named_parameters():
-        if gn[k] > 1e-6 and flips == 0:
+        if gn[k] > 1e-6 and flips == 0 and not is_noise_bias(k):
             assert abs(p.grad.double().norm().item() - gn[k]) <= 5e-4 * gn[k], k
 
 
