@@ -73,22 +73,43 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *__re
     }
 }
 
-__global__ void bn_stats_final_kernel(const float *__restrict__ partial, int nslab, int slab_rows, int64_t M, int C,
-                                      float eps, float momentum, float *mean, float *invstd, float *running_mean,
-                                      float *running_var)
+// 32 lanes per channel: lane j merges its contiguous run of slabs (Chan, double), lane 0 then merges
+// the 32 partial results in lane order.  Fixed order -> bitwise reproducible.
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ partial, int nslab, int slab_rows, int64_t M,
+                                                             int C, float eps, float momentum, float *mean, float *invstd,
+                                                             float *running_mean, float *running_var)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sn[256], smu[256], sm2[256];
+    const int tid = threadIdx.x;
+    const int j = tid & 31;
+    const int c = blockIdx.x * 8 + (tid >> 5);
     double n = 0.0, mu = 0.0, m2 = 0.0;
-    for (int s = 0; s < nslab; ++s) {
-        const int64_t r0 = (int64_t)s * slab_rows;
-        const double ns = (double)(min(M, r0 + slab_rows) - r0);
-        const double ms = partial[(size_t)s * 2 * C + c];
-        const double qs = partial[(size_t)s * 2 * C + C + c];
+    if (c < C) {
+        const int per = (nslab + 31) / 32;
+        const int s0 = j * per, s1 = min(nslab, s0 + per);
+        for (int s = s0; s < s1; ++s) {
+            const int64_t r0 = (int64_t)s * slab_rows;
+            const double ns = (double)(min(M, r0 + slab_rows) - r0);
+            const double ms = partial[(size_t)s * 2 * C + c];
+            const double qs = partial[(size_t)s * 2 * C + C + c];
+            const double tot = n + ns;
+            const double delta = ms - mu;
+            mu += delta * ns / tot;
+            m2 += qs + delta * delta * n * ns / tot;
+            n = tot;
+        }
+    }
+    sn[tid] = n; smu[tid] = mu; sm2[tid] = m2;
+    __syncthreads();
+    if (j != 0 || c >= C) return;
+    n = 0.0; mu = 0.0; m2 = 0.0;
+    for (int k = 0; k < 32; ++k) {
+        const double ns = sn[tid + k];
+        if (ns == 0.0) continue;
         const double tot = n + ns;
-        const double delta = ms - mu;
+        const double delta = smu[tid + k] - mu;
         mu += delta * ns / tot;
-        m2 += qs + delta * delta * n * ns / tot;
+        m2 += sm2[tid + k] + delta * delta * n * ns / tot;
         n = tot;
     }
     const double var_b = m2 / (double)M;
@@ -178,15 +199,26 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float *__rest
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta)
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double r1[256], r2[256];
+    const int tid = threadIdx.x;
+    const int j = tid & 31;
+    const int c = blockIdx.x * 8 + (tid >> 5);
     double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < nslab; ++s) {
-        s1 += (double)partial[(size_t)s * 2 * C + c];
-        s2 += (double)partial[(size_t)s * 2 * C + C + c];
+    if (c < C) {
+        const int per = (nslab + 31) / 32;
+        const int b0 = j * per, b1 = min(nslab, b0 + per);
+        for (int s = b0; s < b1; ++s) {
+            s1 += (double)partial[(size_t)s * 2 * C + c];
+            s2 += (double)partial[(size_t)s * 2 * C + C + c];
+        }
     }
+    r1[tid] = s1; r2[tid] = s2;
+    __syncthreads();
+    if (j != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int k = 0; k < 32; ++k) { s1 += r1[tid + k]; s2 += r2[tid + k]; }
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
 }
@@ -247,7 +279,7 @@ int nsg_bn_stats(const float *x, int64_t M, int32_t C, float eps, float momentum
     hipStream_t s = (hipStream_t)stream;
     float *partial = reinterpret_cast<float *>(workspace);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, g.nslab, g.rows, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, g.rows, M, C, eps,
                        momentum, mean, invstd, running_mean, running_var);
     return nsg_check_launch("bn_stats");
 }
@@ -291,7 +323,7 @@ int nsg_bn_backward(const float *x, const float *y_relu, const float *dy, const 
     hipStream_t s = (hipStream_t)stream;
     float *partial = reinterpret_cast<float *>(workspace);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.nslab), dim3(256), 0, s, x, y_relu, dy, mean, invstd, M, C, g.rows, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, g.nslab, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
     const int64_t n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y_relu, dy, mean, invstd, gamma, dgamma,
                        dbeta, dx, n4, C / 4, 1.0f / (float)M);

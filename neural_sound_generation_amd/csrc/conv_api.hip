@@ -98,12 +98,49 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
         __syncthreads();
     }
 }
-__global__ void colsum_final_kernel(const float *__restrict__ partial, int nslab, int C, float *out)
+// vector form of the above for C % 4 == 0: thread (cg, rg) owns 4 channels of every rgroups-th row
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float *__restrict__ x, int64_t M, int C, int slab_rows,
+                                                                 float *__restrict__ partial)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int C4 = C >> 2;
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * slab_rows;
+    const int64_t r1 = min(M, r0 + slab_rows);
+    for (int cb = 0; cb < C4; cb += 256) {          // C <= 1024 -> a single pass
+        const int cw = min(256, C4 - cb);
+        const int rgroups = 256 / cw;
+        const int cg = tid % cw, rg = tid / cw;
+        v4f s = {0.f, 0.f, 0.f, 0.f};
+        if (rg < rgroups)
+            for (int64_t r = r0 + rg; r < r1; r += rgroups) s += *reinterpret_cast<const v4f *>(x + r * C + (cb + cg) * 4);
+        if (rg < rgroups) *reinterpret_cast<v4f *>(red + (rg * cw + cg) * 4) = s;
+        __syncthreads();
+        if (tid < cw) {
+            v4f t = {0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < rgroups; ++g) t += *reinterpret_cast<const v4f *>(red + (g * cw + tid) * 4);
+            *reinterpret_cast<v4f *>(partial + (size_t)blockIdx.x * C + (cb + tid) * 4) = t;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ partial, int nslab, int C, float *out)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int j = tid & 31;
+    const int c = blockIdx.x * 8 + (tid >> 5);
     double s = 0.0;
-    for (int i = 0; i < nslab; ++i) s += (double)partial[(size_t)i * C + c];
+    if (c < C) {
+        const int per = (nslab + 31) / 32;
+        const int b0 = j * per, b1 = min(nslab, b0 + per);
+        for (int i = b0; i < b1; ++i) s += (double)partial[(size_t)i * C + c];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (j != 0 || c >= C) return;
+    s = 0.0;
+    for (int k = 0; k < 32; ++k) s += red[tid + k];
     out[c] = (float)s;
 }
 
@@ -124,8 +161,11 @@ int colsum(const float *x, int64_t M, int C, float *out, void *ws, hipStream_t s
 {
     const CsGeom g = cs_geom(M);
     float *partial = reinterpret_cast<float *>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, g.nslab, C, out);
+    if (C % 4 == 0 && nsg_aligned16(x))
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, out);
     return nsg_check_launch("colsum");
 }
 
