@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the data-parallel wiring (flat bucket, one sum all-reduce, 1/R in
+the update, parameter broadcast, clip sharding).  Gradients come from the oracle here (kernels need
+a GPU); the result must equal the reference-generated DP fixture (tests/golden/model_tiny.npz dp.*)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, golden_path, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neural_sound_generation_amd import distributed as D, models as M
+    from neural_sound_generation_amd.optim import FlatAdam
+    from oracle import vqvae_oracle as O
+
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world
+    g = np.load(golden_path)
+    model = M.VQVAE(1, 16, 32)
+    if rank == 0:   # only rank 0 holds the real weights; broadcast must replicate them
+        model.load_state_dict({k[4:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd0.")})
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    D.broadcast_flat(opt.flat_param, 0)
+    for b_ in model.buffers():
+        dist.broadcast(b_, 0)
+    batch = torch.cat([torch.from_numpy(g["dp.c0"]), torch.from_numpy(g["dp.c1"])])
+    c = D.shard_batch(batch, rank, world)
+    st = O.clone_state(model.state_dict())
+    rec = O.forward_backward(st, c)                 # per-rank BatchNorm statistics
+    opt.zero_grad()
+    for (k, p) in model.named_parameters():
+        p.grad.copy_(rec["grads"][k])               # what the HIP backward writes into the bucket
+    D.allreduce_sum_(opt.flat_grad)                 # ONE collective for the whole model
+    avg = {k: p.grad / world for k, p in model.named_parameters()}
+    if rank == 0:
+        losses = [rec["loss_recons"].item(), rec["loss_vq"].item(), rec["loss_commit"].item()]
+        ostate = O.adam_init(st)
+        O.adam_step(st, avg, ostate, lr=1e-3)       # the Adam kernel's arithmetic, grad_scale = 1/R
+        np.savez(out_path, losses=np.array(losses), **{"grad." + k: v.numpy() for k, v in avg.items()},
+                 **{"sd1." + k: v.numpy() for k, v in st.items() if O.is_param(k)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_matches_reference_fixture(tmp_path, golden_dir):
+    golden_path = os.path.join(golden_dir, "model_tiny.npz")
+    out_path = str(tmp_path / "dp_out.npz")
+    mp.spawn(_worker, args=(2, _free_port(), golden_path, out_path), nprocs=2, join=True)
+    g, got = np.load(golden_path), np.load(out_path)
+    np.testing.assert_allclose(got["losses"], g["dp.losses"][0], rtol=1e-6)
+    noise_bias = ("encoder.0.bias", "block.1.bias", "block.4.bias", "decoder.3.bias")  # exact-zero gradients (bias before a BN)
+    for k in [f[5:] for f in got.files if f.startswith("grad.")]:
+        if k.endswith(noise_bias):
+            assert float(np.abs(got["grad." + k]).max()) < 1e-4
+            continue
+        want = g["dp.grad." + k]   # the CPU thread count changes ATen's summation order: compare at the tensor's scale
+        np.testing.assert_allclose(got["grad." + k], want, rtol=1e-4, atol=2e-5 * max(float(np.abs(want).max()), 1e-6), err_msg=k)
+        big = np.abs(g["dp.grad." + k]) > 1e-5
+        np.testing.assert_allclose(got["sd1." + k][big], g["dp.sd1." + k][big], rtol=0, atol=2e-6, err_msg=k)
