@@ -4,40 +4,48 @@
 //
 // One kernel serves nn.Conv2d forward, nn.ConvTranspose2d forward and both of their data
 // gradients (reference call sites: src/models.py:150,153,165,168,179,182 and their autograd):
-//   mode 0 ("conv gather"):   input pixel = (ry*stride - pad + kh, rx*stride - pad + kw)
-//   mode 1 ("transposed 4/2/1"): the 4 output parity classes (oy&1, ox&1) each use their own 2x2
+//   MODE 0 ("conv gather"):   input pixel = (ry*stride - pad + kh, rx*stride - pad + kw)
+//   MODE 1 ("transposed 4/2/1"): the 4 output parity classes (oy&1, ox&1) each use their own 2x2
 //       subset of the 4x4 taps; one class per blockIdx.y, so every row of a tile shares its taps.
 //
 // Layout / mapping (MI355X-first, not a port of anything):
 //   * activations NHWC, so a K-chunk (32 channels of one tap) of a row is 128 contiguous bytes;
-//   * block = 256 threads = 4 waves, tile BM x BN = (WM*TM*32) x (WN*TN*32), each wave owns
-//     TM x TN accumulators of 32x32 (v16f each);
+//   * block = 256 threads = 4 waves (one per SIMD), tile BM x BN = (WM*TM*32) x (WN*TN*32), each
+//     wave owns TM x TN accumulators of 32x32 (v16f each, in AGPRs);
 //   * A (gathered input rows) and B (weights, [n][c] so both operands are "row = MFMA row/col,
 //     contiguous k") are register-staged global -> LDS with a 36-float row pitch: the
 //     ds_read_b128 of 16 different rows then lands on 16 different 4-bank groups (conflict-free);
 //   * one lane's ds_read_b128 feeds 4 MFMAs: MFMA q of a chunk-of-8 consumes k = {q, 4+q}
-//     (lane half h supplies k = 4h+q) for both operands, which is a fixed permutation of the
-//     reduction order, identical on both sides;
-//   * double-buffered LDS, next chunk's global loads are issued before the MFMAs of the current.
+//     (lane half h supplies k = 4h+q) for both operands: a fixed permutation of the reduction
+//     order, identical on both sides;
+//   * double-buffered LDS; the steady-state loop body is ONE basic block (MODE / RELU are template
+//     parameters, predicates are branch-free, the last chunk is peeled) so the compiler can issue
+//     the next chunk's address arithmetic, global loads and LDS writes in the shadow of the
+//     current chunk's 64-cycle MFMAs; loads are unconditional (clamped address), zero-fill and
+//     the fused ReLU are applied when the registers are written to LDS;
+//   * epilogue: accumulators -> LDS -> 16-byte row-contiguous stores (the MFMA C layout would
+//     otherwise give 4-byte stores, which leaves the store-bound C=1 layers at a third of HBM rate).
 #include "nsg_common.h"
 
 namespace {
 
-constexpr int LDS_PITCH = 36;  // floats per staged row (32 + 4 pad)
+constexpr int LDS_PITCH = 36;   // floats per staged row (32 + 4 pad)
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int MODE, bool RELU>
 __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
 {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int AJ = BM / 32;  // float4 rows per thread for A
     constexpr int BJ = BN / 32;
+    constexpr int CP = BN + 4;   // epilogue staging pitch (floats)
     static_assert(WM * WN == 4, "4 waves per block");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [2][BM][36]
     float *Bs = smem + 2 * BM * LDS_PITCH;    // [2][BN][36]
     int *rowoff = reinterpret_cast<int *>(Bs + 2 * BN * LDS_PITCH);  // [BM]
+    float *Cs = smem;                         // epilogue: [BM][CP], reuses As/Bs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,8 +75,8 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
             const int ry = rem / p.RW;
             const int rx = rem - ry * p.RW;
             int iy0, ix0;
-            if (p.mode == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad; }
-            else             { iy0 = ry + py;               ix0 = rx + px; }
+            if (MODE == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad; }
+            else           { iy0 = ry + py;               ix0 = rx + px; }
             riy0[j] = iy0;
             rix0[j] = ix0;
             rbase[j] = ((b * p.IH + iy0) * p.IW + ix0) * p.CI;
@@ -87,61 +95,70 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
             const int rem = m - b * (p.RH * p.RW);
             const int ry = rem / p.RW;
             const int rx = rem - ry * p.RW;
-            const int oy = (p.mode == 0) ? ry : 2 * ry + py;
-            const int ox = (p.mode == 0) ? rx : 2 * rx + px;
+            const int oy = (MODE == 0) ? ry : 2 * ry + py;
+            const int ox = (MODE == 0) ? rx : 2 * rx + px;
             if (oy < p.OH && ox < p.OW) off = ((b * p.OH + oy) * p.OW + ox) * p.CO;  // odd extents: last class row/col absent
         }
         rowoff[tid] = off;
     }
 
     const int nchunks = (p.CI + 31) >> 5;
-    const int ntaps = (p.mode == 0) ? p.KH * p.KW : 4;
+    const int ntaps = (MODE == 0) ? p.KH * p.KW : 4;
     const int nit = ntaps * nchunks;
-    const bool relu_in = (p.flags & NSG_RELU_IN) != 0;
 
     v4f ra[AJ], rb[BJ];
+    unsigned okmask = 0;  // bit j: ra[j] is a real element; bit 16+j: rb[j] is
 
-    auto gload = [&](int it) {
-        const int t = it / nchunks;
-        const int c0 = (it - t * nchunks) << 5;
+    // state of the NEXT chunk to load (advanced incrementally: no divisions in the loop)
+    int g_c0 = 0, g_kh = 0, g_kw = 0;   // MODE 0: (kh,kw) of the tap; MODE 1: (a,b2) of the class tap
+    auto gload = [&]() {
         int dy, dx, ws;
-        if (p.mode == 0) {
-            dy = t / p.KW;
-            dx = t - dy * p.KW;
-            ws = t;
-        } else {
-            const int a = t >> 1, b2 = t & 1;
-            dy = -a;
-            dx = -b2;
-            ws = ((1 - py) + 2 * a) * 4 + (1 - px) + 2 * b2;
-        }
+        if (MODE == 0) { dy = g_kh; dx = g_kw; ws = g_kh * p.KW + g_kw; }
+        else           { dy = -g_kh; dx = -g_kw; ws = ((1 - py) + 2 * g_kh) * 4 + (1 - px) + 2 * g_kw; }
+        const int c0 = g_c0;
         const int tapoff = (dy * p.IW + dx) * p.CI + c0 + c4;
-        const bool cok = (c0 + c4) < p.CI;
+        const int cok = (c0 + c4) < p.CI;
+        unsigned m = 0;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int iy = riy0[j] + dy, ix = rix0[j] + dx;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-                v = *reinterpret_cast<const v4f *>(p.in + (rbase[j] + tapoff));
-            if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            ra[j] = v;
+            const int ok = cok & (iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW);
+            const int off = ok ? rbase[j] + tapoff : 0;
+            ra[j] = *reinterpret_cast<const v4f *>(p.in + off);
+            m |= (unsigned)ok << j;
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int n = n0 + rsub + 32 * j;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && n < p.CO)
-                v = *reinterpret_cast<const v4f *>(p.w + ((size_t)(ws * p.CO + n) * p.CI + c0 + c4));
-            rb[j] = v;
+            const int ok = cok & (n < p.CO);
+            const int off = ok ? ((ws * p.CO + n) * p.CI + c0 + c4) : 0;
+            rb[j] = *reinterpret_cast<const v4f *>(p.w + off);
+            m |= (unsigned)ok << (16 + j);
         }
+        okmask = m;
+        // advance to the following chunk
+        g_c0 += 32;
+        const int wrap = g_c0 >= p.CI;
+        g_c0 = wrap ? 0 : g_c0;
+        g_kw += wrap;
+        const int kwlim = (MODE == 0) ? p.KW : 2;
+        const int wrap2 = g_kw >= kwlim;
+        g_kw = wrap2 ? 0 : g_kw;
+        g_kh += wrap2;
     };
     auto lstore = [&](int buf) {
         float *a = As + buf * BM * LDS_PITCH;
         float *b = Bs + buf * BN * LDS_PITCH;
+        const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + c4) = ra[j];
+        for (int j = 0; j < AJ; ++j) {
+            v4f v = (okmask >> j) & 1u ? ra[j] : zero;
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + c4) = v;
+        }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + c4) = rb[j];
+        for (int j = 0; j < BJ; ++j)
+            *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + c4) = (okmask >> (16 + j)) & 1u ? rb[j] : zero;
     };
 
     v16f acc[TM][TN];
@@ -152,13 +169,7 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int it = 0; it < nit; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nit) gload(it + 1);
+    auto compute = [&](int cur) {
         const float *a_base = As + cur * BM * LDS_PITCH + (wr * TM * 32 + l31) * LDS_PITCH + 4 * h;
         const float *b_base = Bs + cur * BN * LDS_PITCH + (wc * TN * 32 + l31) * LDS_PITCH + 4 * h;
 #pragma unroll
@@ -176,52 +187,94 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < nit) lstore(cur ^ 1);
+    };
+
+    gload();
+    lstore(0);
+    __syncthreads();
+
+    // steady state: straight-line body, the scheduler overlaps staging with the MFMAs
+    for (int it = 0; it + 1 < nit; ++it) {
+        const int cur = it & 1;
+        gload();
+        compute(cur);
+        lstore(cur ^ 1);
         __syncthreads();
     }
+    compute((nit - 1) & 1);
+    __syncthreads();   // everyone is done reading As/Bs: the region becomes the output staging tile
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wc * TN * 32 + j * 32 + l31;
-        if (col >= p.CO) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const int col = wc * TN * 32 + j * 32 + l31;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int off = rowoff[row];
-                if (off >= 0) {
-                    float v = acc[i][j][r] + bv;
-                    if (tanh_out) v = tanhf(v);
-                    p.out[(size_t)off + col] = v;
-                }
+                Cs[row * CP + col] = acc[i][j][r];
             }
+    }
+    __syncthreads();
+    const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
+    const bool vec_store = ((p.CO & 3) == 0) && nsg_aligned16_dev(p.out);
+    constexpr int N4 = BN / 4;
+    for (int f = tid; f < BM * N4; f += 256) {
+        const int row = f / N4;
+        const int cq = (f - row * N4) * 4;
+        const int off = rowoff[row];
+        const int col = n0 + cq;
+        if (off < 0 || col >= p.CO) continue;
+        v4f v = *reinterpret_cast<const v4f *>(Cs + row * CP + cq);
+        if (p.bias) {
+            v.x += p.bias[col];
+            if (col + 1 < p.CO) v.y += p.bias[col + 1];
+            if (col + 2 < p.CO) v.z += p.bias[col + 2];
+            if (col + 3 < p.CO) v.w += p.bias[col + 3];
+        }
+        if (tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        float *dst = p.out + (size_t)off + col;
+        if (vec_store && col + 3 < p.CO) {
+            *reinterpret_cast<v4f *>(dst) = v;
+        } else {
+            dst[0] = v.x;
+            if (col + 1 < p.CO) dst[1] = v.y;
+            if (col + 2 < p.CO) dst[2] = v.z;
+            if (col + 3 < p.CO) dst[3] = v.w;
         }
     }
+}
+
+template <int WM, int WN, int TM, int TN, int MODE, bool RELU>
+int launch_one(const GatherGemmParams &p, hipStream_t s)
+{
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t STAGE_FLOATS = (size_t)2 * BM * LDS_PITCH + (size_t)2 * BN * LDS_PITCH;
+    static_assert((size_t)BM * (BN + 4) <= STAGE_FLOATS, "epilogue tile must fit the staging region");
+    const size_t lds = STAGE_FLOATS * sizeof(float) + BM * sizeof(int);
+    const int ntn = (p.CO + BN - 1) / BN;
+    const int64_t ntm = nsg_cdiv(p.M, BM);
+    const int64_t gx = ntm * ntn;
+    if (gx <= 0 || gx > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: grid too large");
+    dim3 grid((unsigned)gx, MODE == 0 ? 1 : 4, 1);
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
+    if (!attr_set && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_gemm_f32<WM, WN, TM, TN, MODE, RELU>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return nsg_fail((int)e, "gather_gemm: cannot reserve %zu bytes of LDS", lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gather_gemm_f32<WM, WN, TM, TN, MODE, RELU>), grid, dim3(256), lds, s, p);
+    return nsg_check_launch("gather_gemm_f32");
 }
 
 template <int WM, int WN, int TM, int TN>
 int launch_cfg(const GatherGemmParams &p, hipStream_t s)
 {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const size_t lds = (size_t)(2 * BM * LDS_PITCH + 2 * BN * LDS_PITCH) * sizeof(float) + BM * sizeof(int);
-    const int ntn = (p.CO + BN - 1) / BN;
-    const int64_t ntm = nsg_cdiv(p.M, BM);
-    const int64_t gx = ntm * ntn;
-    if (gx <= 0 || gx > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: grid too large");
-    dim3 grid((unsigned)gx, p.mode == 0 ? 1 : 4, 1);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_gemm_f32<WM, WN, TM, TN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "gather_gemm: cannot reserve %zu bytes of LDS", lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gather_gemm_f32<WM, WN, TM, TN>), grid, dim3(256), lds, s, p);
-    return nsg_check_launch("gather_gemm_f32");
+    const bool relu = (p.flags & NSG_RELU_IN) != 0;
+    if (p.mode == 0) return relu ? launch_one<WM, WN, TM, TN, 0, true>(p, s) : launch_one<WM, WN, TM, TN, 0, false>(p, s);
+    return relu ? launch_one<WM, WN, TM, TN, 1, true>(p, s) : launch_one<WM, WN, TM, TN, 1, false>(p, s);
 }
 
 }  // namespace

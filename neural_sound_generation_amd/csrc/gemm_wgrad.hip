@@ -19,7 +19,7 @@ namespace {
 
 constexpr int KP = 32;  // pixels per chunk
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool ONEHOT>
 __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
 {
     constexpr int TA = WM * TM * 32;
@@ -48,31 +48,33 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
     const int mbeg = slab * p.slab_rows;
     const int mend = min(p.Mp, mbeg + p.slab_rows);
     const int nchunk = (mend - mbeg + KP - 1) / KP;
+    const float lbp = p.relu_p ? 0.f : -INFINITY;   // fused ReLU as a branch-free lower bound
+    const float lbq = p.relu_q ? 0.f : -INFINITY;
 
     v4f rp[PJ], rq[QJ];
+    int ridx[PJ];         // one-hot mode: the code of the row this thread stages
+    unsigned okmask = 0;  // bit j: rp[j] real; bit 16+j: rq[j] real
+    int g_mb = mbeg;      // first pixel of the NEXT chunk to load
 
-    auto gload = [&](int ch) {
-        const int mb = mbeg + ch * KP;
+    // Unconditional loads from clamped addresses; zero-fill / ReLU / one-hot expansion are done in
+    // lstore() so no load is followed by a wait, and the steady-state loop is one basic block.
+    auto gload = [&]() {
+        const int mb = g_mb;
+        unsigned mk = 0;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
             const int f = tid + 256 * j;
             const int pix = f / PA4;
             const int a4 = (f - pix * PA4) * 4;
             const int m = mb + pix;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend && (a0 + a4) < p.A) {
-                if (p.onehot) {
-                    const int code = (int)p.idx[m] - (a0 + a4);
-                    v.x = code == 0 ? 1.f : 0.f;
-                    v.y = code == 1 ? 1.f : 0.f;
-                    v.z = code == 2 ? 1.f : 0.f;
-                    v.w = code == 3 ? 1.f : 0.f;
-                } else {
-                    v = *reinterpret_cast<const v4f *>(p.P + ((size_t)m * p.A + a0 + a4));
-                    if (p.relu_p) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
+            const int ok = (m < mend) & ((a0 + a4) < p.A);
+            if (ONEHOT) {
+                ridx[j] = (int)p.idx[ok ? m : mbeg];
+            } else {
+                const size_t off = ok ? ((size_t)m * p.A + a0 + a4) : 0;
+                rp[j] = *reinterpret_cast<const v4f *>(p.P + off);
             }
-            rp[j] = v;
+            mk |= (unsigned)ok << j;
         }
 #pragma unroll
         for (int j = 0; j < QJ; ++j) {
@@ -80,29 +82,48 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             const int pix = f / QC4;
             const int cc4 = (f - pix * QC4) * 4;
             const int m = mb + pix;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend && (c0 + cc4) < p.C) {
-                const int b = m / (p.PH * p.PW);
-                const int rem = m - b * (p.PH * p.PW);
-                const int py = rem / p.PW;
-                const int px = rem - py * p.PW;
-                const int qy = py * p.stride - p.pad + kh;
-                const int qx = px * p.stride - p.pad + kw;
-                if (qy >= 0 && qy < p.QH && qx >= 0 && qx < p.QW) {
-                    v = *reinterpret_cast<const v4f *>(p.Q + (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + cc4));
-                    if (p.relu_q) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
-            }
-            rq[j] = v;
+            const int mm = m < mend ? m : mbeg;
+            const int b = mm / (p.PH * p.PW);
+            const int rem = mm - b * (p.PH * p.PW);
+            const int py = rem / p.PW;
+            const int px = rem - py * p.PW;
+            const int qy = py * p.stride - p.pad + kh;
+            const int qx = px * p.stride - p.pad + kw;
+            const int ok = (m < mend) & ((c0 + cc4) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
+            const size_t off = ok ? (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + cc4) : 0;
+            rq[j] = *reinterpret_cast<const v4f *>(p.Q + off);
+            mk |= (unsigned)ok << (16 + j);
         }
+        okmask = mk;
+        g_mb += KP;
     };
     auto lstore = [&](int buf) {
         float *ps = Ps + buf * KP * TA;
         float *qs = Qs + buf * KP * TC;
+        const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) *reinterpret_cast<v4f *>(ps + (tid + 256 * j) * 4) = rp[j];
+        for (int j = 0; j < PJ; ++j) {
+            v4f v;
+            if (ONEHOT) {
+                const int f = tid + 256 * j;
+                const int a4 = (f - (f / PA4) * PA4) * 4;
+                const int code = ridx[j] - (a0 + a4);
+                v.x = code == 0 ? 1.f : 0.f;
+                v.y = code == 1 ? 1.f : 0.f;
+                v.z = code == 2 ? 1.f : 0.f;
+                v.w = code == 3 ? 1.f : 0.f;
+            } else {
+                v = rp[j];
+                v.x = fmaxf(v.x, lbp); v.y = fmaxf(v.y, lbp); v.z = fmaxf(v.z, lbp); v.w = fmaxf(v.w, lbp);
+            }
+            *reinterpret_cast<v4f *>(ps + (tid + 256 * j) * 4) = (okmask >> j) & 1u ? v : zero;
+        }
 #pragma unroll
-        for (int j = 0; j < QJ; ++j) *reinterpret_cast<v4f *>(qs + (tid + 256 * j) * 4) = rq[j];
+        for (int j = 0; j < QJ; ++j) {
+            v4f v = rq[j];
+            v.x = fmaxf(v.x, lbq); v.y = fmaxf(v.y, lbq); v.z = fmaxf(v.z, lbq); v.w = fmaxf(v.w, lbq);
+            *reinterpret_cast<v4f *>(qs + (tid + 256 * j) * 4) = (okmask >> (16 + j)) & 1u ? v : zero;
+        }
     };
 
     v16f acc[TM][TN];
@@ -113,32 +134,51 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nchunk > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int cur = ch & 1;
-        if (ch + 1 < nchunk) gload(ch + 1);
-        const float *ps = Ps + cur * KP * TA + wr * TM * 32 + l31;
-        const float *qs = Qs + cur * KP * TC + wc * TN * 32 + l31;
+    // operand reads run two MFMA groups ahead of their use: a wave cannot issue past an MFMA the
+    // matrix pipe has not accepted yet, so reads placed right in front of their consumers would
+    // expose the LDS latency once per group
+    auto compute = [&](int cur) {
+        const float *ps = Ps + cur * KP * TA + wr * TM * 32 + l31 + h * TA;
+        const float *qs = Qs + cur * KP * TC + wc * TN * 32 + l31 + h * TC;
+        constexpr int NS = KP / 2;
+        float a[NS][TM], b[NS][TN];
 #pragma unroll
-        for (int s = 0; s < KP / 2; ++s) {
-            const int k = 2 * s + h;
-            float a[TM], b[TN];
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ps[k * TA + i * 32];
+            for (int i = 0; i < TM; ++i) a[s][i] = ps[2 * s * TA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = qs[k * TC + j * 32];
+            for (int j = 0; j < TN; ++j) b[s][j] = qs[2 * s * TC + j * 32];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 2 < NS) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[s + 2][i] = ps[2 * (s + 2) * TA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[s + 2][j] = qs[2 * (s + 2) * TC + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // the next-next group's LDS reads ...
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // ... then this group's MFMAs
         }
-        if (ch + 1 < nchunk) lstore(cur ^ 1);
+    };
+
+    if (nchunk > 0) {
+        gload();
+        lstore(0);
         __syncthreads();
+        for (int ch = 0; ch + 1 < nchunk; ++ch) {
+            const int cur = ch & 1;
+            gload();
+            compute(cur);
+            lstore(cur ^ 1);
+            __syncthreads();
+        }
+        compute((nchunk - 1) & 1);
     }
 
     const int ntaps = p.KH * p.KW;
@@ -158,16 +198,40 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
 }
 
 // dst[(a*C + c)*ntaps + t] = sum_slab partial[slab][t][a][c]
-__global__ void wgrad_reduce_kernel(const float *partial, float *dst, int nslab, int ntaps, int A, int C)
+// One thread per output when there are few slabs; otherwise 8 lanes per output split the slabs and
+// the partial sums are added in lane order (fixed order either way: bitwise reproducible).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dst, int nslab, int ntaps,
+                                                           int A, int C, int split)
 {
+    __shared__ float red[256];
     const int64_t total = (int64_t)ntaps * A * C;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % C);
-        const int a = (int)((e / C) % A);
-        const int t = (int)(e / ((int64_t)A * C));
-        float s = 0.f;
-        for (int sl = 0; sl < nslab; ++sl) s += partial[(size_t)sl * total + e];
-        dst[((size_t)a * C + c) * ntaps + t] = s;
+    const int per_block = 256 / split;
+    const int tid = threadIdx.x;
+    const int sub = tid / per_block;          // which share of the slabs
+    const int loc = tid - sub * per_block;    // which output inside the block (consecutive -> coalesced)
+    for (int64_t e0 = (int64_t)blockIdx.x * per_block; e0 < total; e0 += (int64_t)gridDim.x * per_block) {
+        const int64_t e = e0 + loc;
+        float sacc = 0.f;
+        if (e < total) {
+            const int chunk = (nslab + split - 1) / split;
+            const int s0 = sub * chunk, s1 = min(nslab, s0 + chunk);
+            for (int sl = s0; sl < s1; ++sl) sacc += partial[(size_t)sl * total + e];
+        }
+        if (split > 1) {
+            red[tid] = sacc;
+            __syncthreads();
+            if (sub == 0) {
+                sacc = 0.f;
+                for (int k = 0; k < split; ++k) sacc += red[k * per_block + loc];
+            }
+            __syncthreads();
+        }
+        if (sub == 0 && e < total) {
+            const int c = (int)(e % C);
+            const int a = (int)((e / C) % A);
+            const int t = (int)(e / ((int64_t)A * C));
+            dst[((size_t)a * C + c) * ntaps + t] = sacc;
+        }
     }
 }
 
@@ -181,7 +245,7 @@ SlabPlan plan_slabs(int64_t Mp, int ntaps, int A, int C)
     const int TA = A > 64 ? 128 : (A > 32 ? 64 : 32);  // informational; tiles chosen in dispatch below
     (void)TA;
     const int64_t tiles = nsg_cdiv(A, 128) * nsg_cdiv(C, C > 32 ? 128 : 32) * ntaps;
-    int64_t want = nsg_cdiv(1536, tiles);           // aim for ~6 blocks per CU in total
+    int64_t want = 512 / tiles;                     // ONE full round of the 512 resident blocks (2 per CU): no stragglers, least slab traffic
     const int64_t maxslab = nsg_cdiv(Mp, 256);      // at least 256 pixels per slab
     if (want > maxslab) want = maxslab;
     if (want < 1) want = 1;
@@ -193,8 +257,8 @@ SlabPlan plan_slabs(int64_t Mp, int ntaps, int A, int C)
     return sp;
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
+template <int WM, int WN, int TM, int TN, bool ONEHOT>
+int launch_wg1(const WgradParams &p, int nslab, hipStream_t s)
 {
     constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
     const size_t lds = (size_t)2 * KP * (TA + TC) * sizeof(float);
@@ -203,13 +267,19 @@ int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
     dim3 grid(nslab, ntaps, tiles);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_f32<WM, WN, TM, TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_f32<WM, WN, TM, TN, ONEHOT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_gemm_f32<WM, WN, TM, TN>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((wgrad_gemm_f32<WM, WN, TM, TN, ONEHOT>), grid, dim3(256), lds, s, p);
     return nsg_check_launch("wgrad_gemm_f32");
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
+{
+    return p.onehot ? launch_wg1<WM, WN, TM, TN, true>(p, nslab, s) : launch_wg1<WM, WN, TM, TN, false>(p, nslab, s);
 }
 
 }  // namespace
@@ -241,7 +311,9 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     }
     if (rc != NSG_OK) return rc;
     const int64_t total = (int64_t)ntaps * p.A * p.C;
-    const int blocks = (int)(nsg_cdiv(total, 256) > 2048 ? 2048 : nsg_cdiv(total, 256));
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, dst, sp.nslab, ntaps, p.A, p.C);
+    const int split = (sp.nslab >= 64 && total < 512 * 256) ? 8 : 1;   // few outputs, many slabs: share the slabs
+    const int64_t nb = nsg_cdiv(total, 256 / split);
+    const int blocks = (int)(nb > 4096 ? 4096 : nb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, dst, sp.nslab, ntaps, p.A, p.C, split);
     return nsg_check_launch("wgrad_reduce_kernel");
 }

@@ -108,25 +108,34 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
 
     const int ntiles = (K + 31) / 32;
     v4f re[EJ];
+    unsigned okmask = 0;
+    // unconditional loads (clamped address), zero-fill at LDS-store time: no wait behind a load
     auto gload = [&](int ct) {
+        unsigned mk = 0;
 #pragma unroll
         for (int j = 0; j < EJ; ++j) {
             const int f = tid + 256 * j;       // float4 index inside the [32][DP] tile
             const int cr = f / (DP / 4), d4 = (f - cr * (DP / 4)) * 4;
             const int code = ct * 32 + cr;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (cr < 32 && code < K) {
-                const float *src = e + (size_t)code * D + d4;
-                if (vec_ok && d4 + 3 < D) v = *reinterpret_cast<const v4f *>(src);
-                else {
+            const bool row_ok = cr < 32 && code < K;
+            if (vec_ok) {
+                const bool ok = row_ok && d4 < D;       // D % 4 == 0: whole float4 inside the row
+                re[j] = *reinterpret_cast<const v4f *>(e + (ok ? (size_t)code * D + d4 : 0));
+                mk |= ok ? (1u << j) : 0u;
+            } else {
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if (row_ok) {
+                    const float *src = e + (size_t)code * D + d4;
                     if (d4 + 0 < D) v.x = src[0];
                     if (d4 + 1 < D) v.y = src[1];
                     if (d4 + 2 < D) v.z = src[2];
                     if (d4 + 3 < D) v.w = src[3];
                 }
+                re[j] = v;
+                mk |= 1u << j;
             }
-            re[j] = v;
         }
+        okmask = mk;
     };
     auto lstore = [&](int buf) {
         float *es = Es + buf * 32 * EP;
@@ -135,8 +144,9 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
             const int f = tid + 256 * j;
             const int cr = f / (DP / 4), d4 = (f - cr * (DP / 4)) * 4;
             if (cr < 32) {
+                const bool ok = (okmask >> j) & 1u;
                 float *dst = es + cr * EP + d4;
-                dst[0] = re[j].x; dst[1] = re[j].y; dst[2] = re[j].z; dst[3] = re[j].w;
+                dst[0] = ok ? re[j].x : 0.f; dst[1] = ok ? re[j].y : 0.f; dst[2] = ok ? re[j].z : 0.f; dst[3] = ok ? re[j].w : 0.f;
             }
         }
     };
