@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             const int cc4 = (f - pix * QC4) * 4;
             const int m = mb + pix;
             const int mm = m < mend ? m : mbeg;
-            const int b = mm / (p.PH * p.PW);
+            const int b = nsg_div(mm, p.div_phw);
             const int rem = mm - b * (p.PH * p.PW);
-            const int py = rem / p.PW;
+            const int py = nsg_div(rem, p.div_pw);
             const int px = rem - py * p.PW;
             const int qy = py * p.stride - p.pad + kh;
             const int qx = px * p.stride - p.pad + kw;
@@ -301,6 +301,8 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     if (ws == nullptr || ws_bytes < need) return nsg_fail(NSG_E_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = reinterpret_cast<float *>(ws);
     p.slab_rows = sp.slab_rows;
+    p.div_pw = nsg_fastdiv((uint32_t)p.PW);
+    p.div_phw = nsg_fastdiv((uint32_t)p.PH * (uint32_t)p.PW);
     int rc;
     if (p.C <= 32) {
         rc = launch_wg<4, 1, 1, 1>(p, sp.nslab, s);          // 128 x 32 (im2col'd single-channel layers)

@@ -24,6 +24,27 @@ __device__ __forceinline__ bool nsg_aligned16_dev(const void *p) { return (reint
 static inline int64_t nsg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t nsg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Division of n < 2^31 by a launch-invariant d >= 1 as one 64-bit multiply + shift (exact: with
+// s = ceil(log2 d) and M = ceil(2^(31+s) / d) the error term n*(M*d - 2^(31+s)) stays below 2^(31+s)).
+struct FastDiv {
+    uint32_t mul;
+    uint32_t shift;
+};
+static inline FastDiv nsg_fastdiv(uint32_t d)
+{
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + s);
+    FastDiv f;
+    f.mul = (uint32_t)((num + d - 1) / d);
+    f.shift = 31 + s;
+    return f;
+}
+__device__ __forceinline__ int nsg_div(int n, FastDiv f)
+{
+    return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift);
+}
+
 // ---- implicit-GEMM parameter blocks (gemm_gather.hip / gemm_wgrad.hip) -------------------------
 struct GatherGemmParams {
     const float *in;    // [B][IH][IW][CI]
@@ -50,6 +71,7 @@ struct WgradParams {
     int Mp;         // B*PH*PW
     int slab_rows;  // multiple of 32
     int relu_p, relu_q, onehot;
+    FastDiv div_pw, div_phw;   // filled in by nsg_launch_wgrad
 };
 
 int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
