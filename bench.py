@@ -126,10 +126,16 @@ def main():
         roof = None
         if timer is not None:
             s = timer.summary().get("gather_gemm_f32")
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+            if os.path.exists(pmc) and (D, K, B, T) == (128, 512, 64, 1024):
+                # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes of this
+                # command (scripts/pmc_summary.py; PMC cannot be sampled from inside the timed run)
+                traffic = round(json.load(open(pmc))["hbm_bytes_per_launch"] / 1e9, 3)
             if s:
                 roof = {"bound": "mfma", "kernel": "gather_gemm_f32", "achieved": round(s["tflops"], 2),
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(s["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": None, "launches": s["launches"], "avg_launch_ms": round(s["avg_ms"], 4),
+                        "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/)", "launches": s["launches"], "avg_launch_ms": round(s["avg_ms"], 4),
                         "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
                         "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3)}
         cpu = None
