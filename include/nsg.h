@@ -136,6 +136,16 @@ NSG_API size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d);
 NSG_API int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y,
                              int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
+/* nsg_conv_forward plus the training-mode BatchNorm statistics of its output y in the same pass:
+ * nn.Conv2d / nn.ConvTranspose2d followed by nn.BatchNorm2d (src/models.py:165-166, 150-151,
+ * 153-154, 179-180).  The conv epilogue reduces each 128-row output tile to (count, mean, M2) while
+ * the tile is still in LDS; the tiles are merged exactly as nsg_bn_stats merges its slabs.
+ * mean/invstd/running_* as in nsg_bn_stats.  NSG_TANH_OUT is not allowed here. */
+NSG_API int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias,
+                                     float *y, int32_t flags, float eps, float momentum, float *mean, float *invstd,
+                                     float *running_mean, float *running_var, void *workspace, size_t workspace_bytes,
+                                     void *stream);
+
 /* dx = d loss / d x given dy (autograd of the calls above).  flags: none. */
 NSG_API int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad, float *dx, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);
@@ -169,10 +179,14 @@ NSG_API int nsg_bn_apply(const float *x, const float *mean, const float *invstd,
                          void *stream);
 
 /* Backward of the call above with respect to x, gamma, beta.  y_relu: the forward OUTPUT when
- * relu != 0 was used (its sign is the ReLU mask), else NULL.  dgamma/dbeta [C] overwritten. */
+ * relu != 0 was used (its sign is the ReLU mask), else NULL.  dgamma/dbeta [C] overwritten.
+ * dx_colsum [C] or NULL: column sums of dx, i.e. the bias gradient of the convolution that feeds
+ * this BatchNorm (autograd of nn.Conv2d's bias at src/models.py:150,153,165,179), produced by the
+ * kernel that writes dx instead of a second pass over it. */
 NSG_API int nsg_bn_backward(const float *x, const float *y_relu, const float *dy, const float *mean,
-                            const float *invstd, const float *gamma, float *dx, float *dgamma, float *dbeta, int64_t M,
-                            int32_t C, void *workspace, size_t workspace_bytes, void *stream);
+                            const float *invstd, const float *gamma, float *dx, float *dgamma, float *dbeta,
+                            float *dx_colsum, int64_t M, int32_t C, void *workspace, size_t workspace_bytes,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Element-wise, losses, optimiser                         src/train.py:118-136

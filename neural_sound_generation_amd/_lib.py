@@ -44,13 +44,14 @@ _SIGS = {
     "nsg_pack_conv_weights": (None, [_D, _P, _P, _P, _P]),
     "nsg_conv_workspace_bytes": (c_size_t, [_D]),
     "nsg_conv_forward": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_conv_forward_bnstats": (None, [_D, _P, _P, _P, _P, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_conv_dgrad": (None, [_D, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_conv_wgrad": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "nsg_bn_stats": (None, [_P, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_bn_eval_stats": (None, [_P, _P, c_int32, c_float, _P, _P, _P]),
     "nsg_bn_apply": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
-    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),
     "nsg_add": (None, [_P, _P, _P, c_int64, _P]),

@@ -218,6 +218,14 @@ inline int64_t lowres_pixels(const nsg_conv_desc *d)
 }
 inline size_t patches_bytes(const nsg_conv_desc *d) { return nsg_align_up((size_t)lowres_pixels(d) * 16 * sizeof(float), 256); }
 
+// per-row-tile BatchNorm statistics written by the conv epilogue: [tiles][3][C_out]
+inline size_t stats_tiles_bytes(const nsg_conv_desc *d)
+{
+    const int64_t out_pix = (int64_t)d->B * d->OH * d->OW;
+    const int64_t tiles = d->transposed ? 4 * nsg_cdiv(out_pix / 4 + d->B * (d->OH + d->OW), 128) + 8 : nsg_cdiv(out_pix, 128);
+    return nsg_align_up((size_t)(tiles + 8) * 3 * d->C_out * sizeof(float), 256);
+}
+
 GatherGemmParams gg_1x1(const float *in, const float *w, const float *bias, float *out, int64_t M, int CI, int CO, int flags)
 {
     GatherGemmParams p = {};
@@ -287,11 +295,12 @@ size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d)
     else { A = d->C_in; C = 16; taps = 1; bytes += patches_bytes(d); }
     bytes += nsg_align_up(nsg_wgrad_workspace_bytes(Mp, taps, A, C), 256);
     bytes += colsum_ws_bytes((int64_t)d->B * d->OH * d->OW, d->C_out);
+    bytes += stats_tiles_bytes(d);
     return bytes;
 }
 
-int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y, int32_t flags,
-                     void *workspace, size_t workspace_bytes, void *stream)
+static int conv_forward_impl(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y, int32_t flags,
+                             void *workspace, size_t workspace_bytes, void *stream, float *stats, int *stats_tiles)
 {
     const int kind = classify(d, "nsg_conv_forward");
     if (kind < 0) return kind;
@@ -307,6 +316,8 @@ int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd,
         if (kind == K_CONV) { p.mode = 0; p.RH = d->OH; p.RW = d->OW; }
         else                { p.mode = 1; p.RH = d->IH; p.RW = d->IW; }
         p.M = d->B * p.RH * p.RW;
+        p.stats = stats;
+        if (stats_tiles) *stats_tiles = nsg_gather_gemm_row_tiles(p);
         return nsg_launch_gather_gemm(p, s);
     }
     NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward: workspace too small");
@@ -317,14 +328,43 @@ int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd,
         hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, x, stage, d->B, d->OH, d->OW, d->IH, d->IW);
         int rc = nsg_check_launch("im2col_c1_kernel");
         if (rc) return rc;
-        return nsg_launch_gather_gemm(gg_1x1(stage, w_fwd, bias, y, Mp, 16, d->C_out, flags & NSG_TANH_OUT), s);
+        GatherGemmParams p1 = gg_1x1(stage, w_fwd, bias, y, Mp, 16, d->C_out, flags & NSG_TANH_OUT);
+        p1.stats = stats;
+        if (stats_tiles) *stats_tiles = nsg_gather_gemm_row_tiles(p1);
+        return nsg_launch_gather_gemm(p1, s);
     }
+    NSG_REQUIRE(stats == nullptr, NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: not available for a single-channel output");
     // K_CONVT_C1: per-input-pixel tap products, then the 4-tap gather with bias (+tanh)
     int rc = nsg_launch_gather_gemm(gg_1x1(x, w_fwd, nullptr, stage, Mp, d->C_in, 16, flags & NSG_RELU_IN), s);
     if (rc) return rc;
     hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->OH * d->OW)), dim3(256), 0, s, stage, bias, y, d->B,
                        d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0);
     return nsg_check_launch("col2im_c1_kernel");
+}
+
+int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y, int32_t flags,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    return conv_forward_impl(d, x, w_fwd, bias, y, flags, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y,
+                             int32_t flags, float eps, float momentum, float *mean, float *invstd, float *running_mean,
+                             float *running_var, void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(d && mean && invstd, NSG_E_INVALID, "nsg_conv_forward_bnstats: null pointer");
+    NSG_REQUIRE(!(flags & NSG_TANH_OUT), NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: statistics are of the linear output");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_conv_workspace_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward_bnstats: workspace too small");
+    // the tile statistics live at the END of the workspace (the C=1 staging image uses its start)
+    const size_t tb = stats_tiles_bytes(d);
+    float *tiles = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + nsg_conv_workspace_bytes(d) - tb);
+    int ntiles = 0;
+    int rc = conv_forward_impl(d, x, w_fwd, bias, y, flags, workspace, workspace_bytes, stream, tiles, &ntiles);
+    if (rc) return rc;
+    NSG_REQUIRE((size_t)ntiles * 3 * d->C_out * sizeof(float) <= tb, NSG_E_WORKSPACE, "nsg_conv_forward_bnstats: tile buffer too small");
+    const int64_t M = (int64_t)d->B * d->OH * d->OW;
+    return nsg_bn_stats_from_tiles(tiles, ntiles, M, d->C_out, eps, momentum, mean, invstd, running_mean, running_var,
+                                   (hipStream_t)stream);
 }
 
 int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad, float *dx, int32_t flags, void *workspace,

@@ -58,7 +58,10 @@ struct GatherGemmParams {
     int M;       // rows per class = B*RH*RW
     int RH, RW;  // row grid: conv -> (OH,OW); transposed -> (ceil(OH/2), ceil(OW/2))
     int flags;   // NSG_RELU_IN | NSG_TANH_OUT
+    float *stats;  // optional [n_row_tiles][3][CO]: per row tile (valid-row count, mean, M2 about it) of the OUTPUT
 };
+// number of 128-row tiles (x parity classes) a launch with these parameters produces = rows of `stats`
+int nsg_gather_gemm_row_tiles(const GatherGemmParams &p);
 
 struct WgradParams {
     const float *P;      // [B][PH][PW][A]  tensor on the conv-OUTPUT pixel grid (rows of the reduction)
@@ -79,3 +82,6 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
 size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C);
 // dst[(a*C + c)*ntaps + t] = sum over slabs (fixed order) of partial; dst fully overwritten.
 int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipStream_t s);
+
+int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, float eps, float momentum, float *mean,
+                            float *invstd, float *running_mean, float *running_var, hipStream_t s);

@@ -196,6 +196,25 @@ def conv_forward(d: ConvDesc, x, w_fwd, bias, flags=0, out=None):
     return y
 
 
+def conv_forward_bnstats(d: ConvDesc, x, w_fwd, bias, flags=0, running_mean=None, running_var=None, eps=BN_EPS,
+                         momentum=BN_MOMENTUM, out=None):
+    """conv forward + training-mode BatchNorm statistics of the output in one pass -> (y, mean, invstd)."""
+    _chk(x, "x")
+    if tuple(x.shape) != (d.B, d.IH, d.IW, d.C_in):
+        raise _lib.NsgError(f"conv_forward_bnstats: input shape {tuple(x.shape)} does not match descriptor {d.key()}")
+    y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=torch.float32, device=x.device)
+    mean = torch.empty(d.C_out, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(d.C_out, dtype=torch.float32, device=x.device)
+    ws, nb = _conv_ws(d, x.device)
+    timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
+    t0 = KERNEL_TIMER.begin() if timed else None
+    _lib.call("nsg_conv_forward_bnstats", byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), c_int32(flags), c_float(eps),
+              c_float(momentum), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), c_size_t(nb), _stream())
+    if timed:
+        KERNEL_TIMER.end("gather_gemm_f32", t0, _gemm_flops(d))
+    return y, mean, invstd
+
+
 def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
     _chk(dy, "dy")
     if tuple(dy.shape) != (d.B, d.OH, d.OW, d.C_out):
@@ -254,7 +273,8 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_resid
     return y
 
 
-def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out=None):
+def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out=None, dx_colsum=None):
+    """dx_colsum: optional [C] tensor receiving the column sums of dx (= bias gradient of the conv in front)."""
     _chk(x, "x"); _chk(dy, "dy")
     C = mean.numel()
     M = x.numel() // C
@@ -266,7 +286,7 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
     _lib.call("nsg_bn_backward", _p(x), _p(y_relu), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
-              c_int64(M), c_int32(C), _p(ws), c_size_t(nb), _stream())
+              _p(dx_colsum), c_int64(M), c_int32(C), _p(ws), c_size_t(nb), _stream())
     return dx, dgamma, dbeta
 
 

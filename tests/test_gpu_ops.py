@@ -231,6 +231,37 @@ def test_conv_forward_dgrad_wgrad(case):
     assert torch.equal(dwg, dwg2), "wgrad must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("case", [(2, 10, 12, 8, 8, 3, 1, 1, False), (2, 11, 15, 16, 16, 4, 2, 1, False), (2, 6, 7, 16, 16, 4, 2, 1, True),
+                                  (2, 20, 31, 1, 8, 4, 2, 1, False), (1, 20, 64, 128, 128, 3, 1, 1, False), (1, 8, 16, 256, 256, 4, 2, 1, False),
+                                  (3, 5, 9, 64, 64, 4, 2, 1, True)], ids=str)
+def test_conv_forward_with_fused_bn_statistics(case):
+    """conv + BatchNorm training statistics in one call == conv, then nsg_bn_stats (and == ATen)."""
+    B, IH, IW, Ci, Co, k, s, p, tr = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Ci, IH, IW, generator=g)
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = torch.randn(*wshape, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    y = F.conv_transpose2d(x, w, b, stride=s, padding=p) if tr else F.conv2d(x, w, b, stride=s, padding=p)
+    rm, rv = torch.zeros(Co), torch.ones(Co)
+    F.batch_norm(y, rm, rv, None, None, True, 0.1, 1e-5)
+    d = ops.conv_desc(B, IH, IW, Ci, Co, k, s, p, transposed=tr)
+    wf, _ = ops.pack_weights(d, gpu(w))
+    rmg, rvg = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    yg, mean, invstd = ops.conv_forward_bnstats(d, gpu(nhwc(x)), wf, gpu(b), running_mean=rmg, running_var=rvg)
+    _close(nchw(yg.cpu()), y, what="forward")
+    want_mean = y.double().mean(dim=(0, 2, 3))
+    want_var = y.double().var(dim=(0, 2, 3), unbiased=False)
+    std = float(want_var.sqrt().max())          # a mean is only meaningful to ~1e-6 of the column's spread
+    np.testing.assert_allclose(mean.cpu().numpy(), want_mean.numpy(), rtol=1e-5, atol=2e-6 * std + 1e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(want_var + 1e-5)).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(rmg.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=2e-7 * std + 1e-6)
+    np.testing.assert_allclose(rvg.cpu().numpy(), rv.numpy(), rtol=2e-5, atol=1e-6)
+    m2, i2 = ops.bn_stats(yg, Co)
+    np.testing.assert_allclose(mean.cpu().numpy(), m2.cpu().numpy(), rtol=1e-5, atol=2e-6 * std + 1e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), i2.cpu().numpy(), rtol=1e-5)
+
+
 def test_conv_rejects_unsupported_geometry():
     from neural_sound_generation_amd._lib import NsgError
     d = ops.conv_desc(1, 8, 8, 6, 8, 3, 1, 1)  # C_in not a multiple of 4
@@ -275,6 +306,12 @@ def test_batchnorm_train_forward_backward(B, C, H, W, relu, res):
     ybn = ops.bn_apply(xg, mean, invstd, gpu(gamma.detach()), gpu(beta.detach()), relu=relu) if relu else None
     dxg, dgg, dbg = ops.bn_backward(xg, ybn, gpu(nhwc(dy)), mean, invstd, gpu(gamma.detach()))
     _close(nchw(dxg.cpu()), gx, tol=3e-5, what="bn dx")
+    # the fused column sum of dx (bias gradient of the conv in front): same dx, plus sum over rows
+    cs = torch.empty(C, device=DEV)
+    dxg2, _, _ = ops.bn_backward(xg, ybn, gpu(nhwc(dy)), mean, invstd, gpu(gamma.detach()), dx_colsum=cs)
+    _close(dxg2.cpu(), dxg.cpu(), tol=1e-6, what="bn dx (colsum variant)")
+    want_cs = dxg.double().sum(dim=(0, 1, 2)).cpu()
+    assert float((cs.cpu().double() - want_cs).abs().max()) <= 1e-5 * float(dxg.abs().sum(dim=(0, 1, 2)).max()) + 1e-7
     _close(dgg.cpu(), gg, tol=3e-5, what="bn dgamma")
     _close(dbg.cpu(), gb, tol=3e-5, what="bn dbeta")
 
