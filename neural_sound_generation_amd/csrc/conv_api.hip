@@ -3,6 +3,10 @@
 // Reference call sites: src/models.py:150,153,165,168 (nn.Conv2d), :179,182 (nn.ConvTranspose2d).
 #include "nsg_common.h"
 
+// diagnostics: when set, the next gather_gemm launches stamp their main-loop clocks into this buffer
+static unsigned long long *g_debug_stamps = nullptr;
+extern "C" NSG_API void nsg_debug_set_stamp_buffer(unsigned long long *buf) { g_debug_stamps = buf; }
+
 namespace {
 
 // dst[(t*NN + n)*CC + c] = src[n*sn + c*sc + (flip ? T-1-t : t)]
@@ -317,6 +321,7 @@ static int conv_forward_impl(const nsg_conv_desc *d, const float *x, const float
         else                { p.mode = 1; p.RH = d->IH; p.RW = d->IW; }
         p.M = d->B * p.RH * p.RW;
         p.stats = stats;
+        p.stamps = g_debug_stamps;
         if (stats_tiles) *stats_tiles = nsg_gather_gemm_row_tiles(p);
         return nsg_launch_gather_gemm(p, s);
     }

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
         }
     };
 
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (p.stamps) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+
     gload();
     lstore(0);
     __syncthreads();
@@ -202,6 +205,11 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
         __syncthreads();
     }
     compute((nit - 1) & 1);
+    if (p.stamps && tid == 0) {   // diagnostics: never read by any kernel
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+        p.stamps[2 * bid] = __builtin_amdgcn_s_memtime() - st_t0;
+        p.stamps[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
     __syncthreads();   // everyone is done reading As/Bs: the region becomes the output staging tile
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----

@@ -14,12 +14,20 @@
 // copies, and an MFMA operand read is 32 consecutive floats of one pixel row (ds_read_b32,
 // conflict-free).  Block = 4 waves, tile TA x TC of one tap for one slab of pixels.
 #include "nsg_common.h"
+#include <type_traits>
+
+static unsigned long long *g_wgrad_stamps = nullptr;   // diagnostics
+static int g_wgrad_diag = 0;
+static int g_wgrad_stagger = 0;
+extern "C" NSG_API void nsg_debug_set_wgrad_stagger(int units) { g_wgrad_stagger = units; }
+extern "C" NSG_API void nsg_debug_set_wgrad_diag(int on) { g_wgrad_diag = on; }
+extern "C" NSG_API void nsg_debug_set_wgrad_stamp_buffer(unsigned long long *buf) { g_wgrad_stamps = buf; }
 
 namespace {
 
 constexpr int KP = 32;  // pixels per chunk
 
-template <int WM, int WN, int TM, int TN, bool ONEHOT>
+template <int WM, int WN, int TM, int TN, bool ONEHOT, bool DIAG = false>
 __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
 {
     constexpr int TA = WM * TM * 32;
@@ -51,14 +59,17 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
     const float lbp = p.relu_p ? 0.f : -INFINITY;   // fused ReLU as a branch-free lower bound
     const float lbq = p.relu_q ? 0.f : -INFINITY;
 
-    v4f rp[PJ], rq[QJ];
-    int ridx[PJ];         // one-hot mode: the code of the row this thread stages
-    unsigned okmask = 0;  // bit j: rp[j] real; bit 16+j: rq[j] real
-    int g_mb = mbeg;      // first pixel of the NEXT chunk to load
+    // two staging register sets: loads run TWO chunks ahead of the MFMAs (both operands stream from
+    // HBM/MALL with no reuse inside a block, so one chunk of distance does not cover their latency)
+    v4f rp[2][PJ], rq[2][QJ];
+    int ridx[2][PJ];          // one-hot mode: the code of the row this thread stages
+    unsigned okmask[2] = {0, 0};  // bit j: rp[j] real; bit 16+j: rq[j] real
+    int g_mb = mbeg;          // first pixel of the NEXT chunk to load
 
     // Unconditional loads from clamped addresses; zero-fill / ReLU / one-hot expansion are done in
     // lstore() so no load is followed by a wait, and the steady-state loop is one basic block.
-    auto gload = [&]() {
+    auto gload = [&](auto set_c) {
+        constexpr int S = decltype(set_c)::value;
         const int mb = g_mb;
         unsigned mk = 0;
 #pragma unroll
@@ -69,10 +80,10 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             const int m = mb + pix;
             const int ok = (m < mend) & ((a0 + a4) < p.A);
             if (ONEHOT) {
-                ridx[j] = (int)p.idx[ok ? m : mbeg];
+                ridx[S][j] = (int)p.idx[ok ? m : mbeg];
             } else {
                 const size_t off = ok ? ((size_t)m * p.A + a0 + a4) : 0;
-                rp[j] = *reinterpret_cast<const v4f *>(p.P + off);
+                rp[S][j] = *reinterpret_cast<const v4f *>(p.P + off);
             }
             mk |= (unsigned)ok << j;
         }
@@ -91,13 +102,14 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             const int qx = px * p.stride - p.pad + kw;
             const int ok = (m < mend) & ((c0 + cc4) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
             const size_t off = ok ? (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + cc4) : 0;
-            rq[j] = *reinterpret_cast<const v4f *>(p.Q + off);
+            rq[S][j] = *reinterpret_cast<const v4f *>(p.Q + off);
             mk |= (unsigned)ok << (16 + j);
         }
-        okmask = mk;
+        okmask[S] = mk;
         g_mb += KP;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto set_c) {
+        constexpr int S = decltype(set_c)::value;
         float *ps = Ps + buf * KP * TA;
         float *qs = Qs + buf * KP * TC;
         const v4f zero = {0.f, 0.f, 0.f, 0.f};
@@ -107,22 +119,22 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             if (ONEHOT) {
                 const int f = tid + 256 * j;
                 const int a4 = (f - (f / PA4) * PA4) * 4;
-                const int code = ridx[j] - (a0 + a4);
+                const int code = ridx[S][j] - (a0 + a4);
                 v.x = code == 0 ? 1.f : 0.f;
                 v.y = code == 1 ? 1.f : 0.f;
                 v.z = code == 2 ? 1.f : 0.f;
                 v.w = code == 3 ? 1.f : 0.f;
             } else {
-                v = rp[j];
+                v = rp[S][j];
                 v.x = fmaxf(v.x, lbp); v.y = fmaxf(v.y, lbp); v.z = fmaxf(v.z, lbp); v.w = fmaxf(v.w, lbp);
             }
-            *reinterpret_cast<v4f *>(ps + (tid + 256 * j) * 4) = (okmask >> j) & 1u ? v : zero;
+            *reinterpret_cast<v4f *>(ps + (tid + 256 * j) * 4) = (okmask[S] >> j) & 1u ? v : zero;
         }
 #pragma unroll
         for (int j = 0; j < QJ; ++j) {
-            v4f v = rq[j];
+            v4f v = rq[S][j];
             v.x = fmaxf(v.x, lbq); v.y = fmaxf(v.y, lbq); v.z = fmaxf(v.z, lbq); v.w = fmaxf(v.w, lbq);
-            *reinterpret_cast<v4f *>(qs + (tid + 256 * j) * 4) = (okmask >> (16 + j)) & 1u ? v : zero;
+            *reinterpret_cast<v4f *>(qs + (tid + 256 * j) * 4) = (okmask[S] >> (16 + j)) & 1u ? v : zero;
         }
     };
 
@@ -134,51 +146,91 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // operand reads run two MFMA groups ahead of their use: a wave cannot issue past an MFMA the
-    // matrix pipe has not accepted yet, so reads placed right in front of their consumers would
-    // expose the LDS latency once per group
+    // Operands for 4 reduction steps (16 MFMAs) are fetched per batch into one of two register sets;
+    // the NEXT batch's LDS reads are pinned into the middle of the current batch's MFMAs
+    // (sched_group_barrier), so their latency is covered by >= 8 MFMAs (512 cycles) of queued work.
+    // A wave cannot issue past an MFMA the matrix pipe has not accepted, so reads placed right in
+    // front of their consumers expose ~60 cycles of LDS latency per 4-MFMA group (measured: 75 % of
+    // the pipe instead of 95 %).
     auto compute = [&](int cur) {
         const float *ps = Ps + cur * KP * TA + wr * TM * 32 + l31 + h * TA;
         const float *qs = Qs + cur * KP * TC + wc * TN * 32 + l31 + h * TC;
-        constexpr int NS = KP / 2;
-        float a[NS][TM], b[NS][TN];
+        constexpr int NB = KP / 8;   // batches of 4 steps
+        float a[2][4][TM], b[2][4][TN];
+        auto fetch = [&](int kk, int set) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[s][i] = ps[2 * s * TA + i * 32];
+                for (int i = 0; i < TM; ++i) a[set][u][i] = ps[2 * (4 * kk + u) * TA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[s][j] = qs[2 * s * TC + j * 32];
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (s + 2 < NS) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[s + 2][i] = ps[2 * (s + 2) * TA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[s + 2][j] = qs[2 * (s + 2) * TC + j * 32];
+                for (int j = 0; j < TN; ++j) b[set][u][j] = qs[2 * (4 * kk + u) * TC + j * 32];
             }
+        };
+        fetch(0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int kk = 0; kk < NB; ++kk) {
+            const int set = kk & 1;
+            if (kk + 1 < NB) fetch(kk + 1, set ^ 1);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // the next-next group's LDS reads ...
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // ... then this group's MFMAs
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][u][i], b[set][u][j], acc[i][j], 0, 0, 0);
+            // order inside this batch: first half of the MFMAs, then the next batch's reads, then the rest
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+            if (kk + 1 < NB) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);   // ds_read2_b32: 2 values per instruction
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
         }
     };
 
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (p.stamps) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (p.stagger > 0) {
+        // Two blocks share each CU and run the same program: started together they want the matrix pipe
+        // -- and then stage -- at the same times.  Delaying the later-dispatched block of each pair by a
+        // fraction of a chunk puts one block's MFMA phase beside the other's staging phase.
+        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int nblk = gridDim.x * gridDim.y * gridDim.z;
+        if (bid >= nblk / 2)
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
     if (nchunk > 0) {
-        gload();
-        lstore(0);
+        // chunk c travels: gload -> register set (c & 1) -> lstore -> LDS buffer (c & 1) -> compute.
+        // Iteration c: store chunk c+1 (loaded two iterations ago), re-issue that register set for
+        // chunk c+3, then the MFMAs of chunk c.  Loads past the slab's end are clamped no-ops.
+        gload(S0{});                 // chunk 0
+        lstore(0, S0{});
+        gload(S1{});                 // chunk 1
+        gload(S0{});                 // chunk 2
         __syncthreads();
-        for (int ch = 0; ch + 1 < nchunk; ++ch) {
-            const int cur = ch & 1;
-            gload();
-            compute(cur);
-            lstore(cur ^ 1);
+        int ch = 0;
+        for (; ch + 2 < nchunk; ch += 2) {
+            lstore(1, S1{});         // chunk ch+1
+            gload(S1{});             // chunk ch+3
+            compute(0);              // chunk ch
+            __syncthreads();
+            lstore(0, S0{});         // chunk ch+2
+            gload(S0{});             // chunk ch+4
+            compute(1);              // chunk ch+1
             __syncthreads();
         }
-        compute((nchunk - 1) & 1);
+        if (ch + 1 < nchunk) {       // two chunks left: ch (in LDS 0) and ch+1 (in register set 1)
+            lstore(1, S1{});
+            compute(0);
+            __syncthreads();
+            compute(1);
+        } else {                     // one chunk left, already in LDS 0
+            compute(0);
+        }
+    }
+    if (p.stamps && tid == 0) {   // diagnostics: never read by any kernel
+        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        p.stamps[2 * bid] = __builtin_amdgcn_s_memtime() - st_t0;
+        p.stamps[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
 
     const int ntaps = p.KH * p.KW;
@@ -277,6 +329,16 @@ int launch_wg1(const WgradParams &p, int nslab, hipStream_t s)
 }
 
 template <int WM, int WN, int TM, int TN>
+int launch_wg_diag(const WgradParams &p, int nslab, hipStream_t s)
+{
+    constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
+    const size_t lds = (size_t)2 * KP * (TA + TC) * sizeof(float);
+    dim3 grid(nslab, p.KH * p.KW, (unsigned)(nsg_cdiv(p.A, TA) * nsg_cdiv(p.C, TC)));
+    hipLaunchKernelGGL((wgrad_gemm_f32<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
+    return nsg_check_launch("wgrad_gemm_f32<diag>");
+}
+
+template <int WM, int WN, int TM, int TN>
 int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
 {
     return p.onehot ? launch_wg1<WM, WN, TM, TN, true>(p, nslab, s) : launch_wg1<WM, WN, TM, TN, false>(p, nslab, s);
@@ -301,6 +363,8 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     if (ws == nullptr || ws_bytes < need) return nsg_fail(NSG_E_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = reinterpret_cast<float *>(ws);
     p.slab_rows = sp.slab_rows;
+    p.stamps = g_wgrad_stamps;
+    p.stagger = g_wgrad_stagger;
     p.div_pw = nsg_fastdiv((uint32_t)p.PW);
     p.div_phw = nsg_fastdiv((uint32_t)p.PH * (uint32_t)p.PW);
     int rc;
@@ -308,6 +372,8 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
         rc = launch_wg<4, 1, 1, 1>(p, sp.nslab, s);          // 128 x 32 (im2col'd single-channel layers)
     } else if (p.A <= 64 && p.C <= 64) {
         rc = launch_wg<2, 2, 1, 1>(p, sp.nslab, s);          // 64 x 64
+    } else if (g_wgrad_diag && p.stamps && !p.onehot) {
+        rc = launch_wg_diag<2, 2, 2, 2>(p, sp.nslab, s);     // diagnostics build of the 128 x 128 kernel
     } else {
         rc = launch_wg<2, 2, 2, 2>(p, sp.nslab, s);          // 128 x 128
     }

@@ -58,6 +58,7 @@ struct GatherGemmParams {
     int M;       // rows per class = B*RH*RW
     int RH, RW;  // row grid: conv -> (OH,OW); transposed -> (ceil(OH/2), ceil(OW/2))
     int flags;   // NSG_RELU_IN | NSG_TANH_OUT
+    unsigned long long *stamps;  // diagnostics only: per block (shader cycles, 100 MHz ticks) spent in the main loop
     float *stats;  // optional [n_row_tiles][3][CO]: per row tile (valid-row count, mean, M2 about it) of the OUTPUT
 };
 // number of 128-row tiles (x parity classes) a launch with these parameters produces = rows of `stats`
@@ -75,6 +76,8 @@ struct WgradParams {
     int slab_rows;  // multiple of 32
     int relu_p, relu_q, onehot;
     FastDiv div_pw, div_phw;   // filled in by nsg_launch_wgrad
+    unsigned long long *stamps;  // diagnostics only
+    int stagger;                 // s_sleep units (64 cycles) the second-dispatched half of the grid waits at start
 };
 
 int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
