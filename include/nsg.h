@@ -201,6 +201,15 @@ NSG_API int nsg_tanh_backward(const float *g, const float *y, float *dx, int64_t
 /* y = a + b (b may be NULL -> copy). */
 NSG_API int nsg_add(const float *a, const float *b, float *y, int64_t n, void *stream);
 
+/* Speaker-conditioned decoder (extension; BASELINE configs[2]; not in the reference, whose VQVAE
+ * ignores the speaker id g, src/train.py:114):  y[b][r][:] = x[b][r][:] + rows[b][:] for the
+ * rows_per_clip pixels r of clip b, and its gradient w.r.t. rows: out[b][:] = sum_r x[b][r][:]. */
+NSG_API int nsg_add_per_clip(const float *x, const float *rows, float *y, int32_t B, int64_t rows_per_clip, int32_t C,
+                             void *stream);
+NSG_API size_t nsg_clip_colsum_workspace_bytes(int32_t B, int32_t C);
+NSG_API int nsg_clip_colsum(const float *x, int32_t B, int64_t rows_per_clip, int32_t C, float *out, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
 NSG_API size_t nsg_reduce_workspace_bytes(int64_t n);
 
 /* loss_out[0] = mean over rows*wc elements of (pad(a) - c)^2 where a is [rows][wa], c is [rows][wc],

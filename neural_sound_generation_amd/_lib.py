@@ -55,6 +55,9 @@ _SIGS = {
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),
     "nsg_add": (None, [_P, _P, _P, c_int64, _P]),
+    "nsg_add_per_clip": (None, [_P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    "nsg_clip_colsum_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "nsg_clip_colsum": (None, [_P, c_int32, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "nsg_reduce_workspace_bytes": (c_size_t, [c_int64]),
     "nsg_mse_padded": (None, [_P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, c_size_t, _P]),
     "nsg_vq_losses": (None, [_P, _P, c_int64, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -157,6 +157,54 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
     }
 }
 
+// y[b][r][:] = x[b][r][:] + rows[b][:]   (speaker embedding broadcast over a clip's pixels)
+__global__ __launch_bounds__(256) void add_per_clip_kernel(const float *__restrict__ x, const float *__restrict__ rows, float *__restrict__ y,
+                                                           int64_t n4, int C4, int64_t per_clip4)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per_clip4;
+        const int c = (int)(i % C4);
+        const v4f r = *reinterpret_cast<const v4f *>(rows + (b * C4 + c) * 4);
+        *reinterpret_cast<v4f *>(y + i * 4) = *reinterpret_cast<const v4f *>(x + i * 4) + r;
+    }
+}
+
+// partial[b][s][:] = sum of rows [s*R, (s+1)*R) of clip b;  then out[b][:] = sum_s partial (fixed order)
+__global__ __launch_bounds__(256) void clip_colsum_partial_kernel(const float *__restrict__ x, int rows_per_clip, int C, int slabs,
+                                                                  float *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int C4 = C >> 2;
+    const int rgroups = 256 / C4;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, rg = tid / C4;
+    const int b = blockIdx.x / slabs, sl = blockIdx.x % slabs;
+    const int R = (rows_per_clip + slabs - 1) / slabs;
+    const int r0 = sl * R, r1 = min(rows_per_clip, r0 + R);
+    const float *base = x + (size_t)b * rows_per_clip * C;
+    v4f s = {0.f, 0.f, 0.f, 0.f};
+    if (rg < rgroups) {
+        for (int r = r0 + rg; r < r1; r += rgroups) s += *reinterpret_cast<const v4f *>(base + (size_t)r * C + cg * 4);
+        *reinterpret_cast<v4f *>(red + (rg * C4 + cg) * 4) = s;
+    }
+    __syncthreads();
+    if (tid < C4) {
+        v4f t = {0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < rgroups; ++g) t += *reinterpret_cast<const v4f *>(red + (g * C4 + tid) * 4);
+        *reinterpret_cast<v4f *>(partial + (size_t)blockIdx.x * C + tid * 4) = t;
+    }
+}
+__global__ void clip_colsum_final_kernel(const float *__restrict__ partial, int B, int slabs, int C, float *__restrict__ out)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int b = (int)(i / C), c = (int)(i % C);
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += partial[((size_t)b * slabs + k) * C + c];
+    out[i] = s;
+}
+
+constexpr int CLIP_SLABS = 16;
 constexpr int RED_BLOCKS = 1024;
 
 }  // namespace
@@ -197,6 +245,33 @@ int nsg_add(const float *a, const float *b, float *y, int64_t n, void *stream)
     else
         hipLaunchKernelGGL((add_kernel<1>), dim3(ew_blocks(n)), dim3(256), 0, s, a, b, y, n);
     return nsg_check_launch("add_kernel");
+}
+
+int nsg_add_per_clip(const float *x, const float *rows, float *y, int32_t B, int64_t rows_per_clip, int32_t C, void *stream)
+{
+    NSG_REQUIRE(x && rows && y && B > 0 && rows_per_clip > 0 && C > 0, NSG_E_INVALID, "nsg_add_per_clip: bad argument");
+    NSG_REQUIRE(C % 4 == 0 && nsg_aligned16(x) && nsg_aligned16(rows) && nsg_aligned16(y), NSG_E_UNSUPPORTED,
+                "nsg_add_per_clip: C must be a multiple of 4 and pointers 16-byte aligned");
+    const int64_t n4 = (int64_t)B * rows_per_clip * C / 4;
+    hipLaunchKernelGGL(add_per_clip_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, rows, y, n4, C / 4,
+                       rows_per_clip * (C / 4));
+    return nsg_check_launch("add_per_clip_kernel");
+}
+
+size_t nsg_clip_colsum_workspace_bytes(int32_t B, int32_t C) { return (size_t)(B > 0 ? B : 0) * CLIP_SLABS * (C > 0 ? C : 0) * sizeof(float); }
+
+int nsg_clip_colsum(const float *x, int32_t B, int64_t rows_per_clip, int32_t C, float *out, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(x && out && B > 0 && rows_per_clip > 0 && C > 0, NSG_E_INVALID, "nsg_clip_colsum: bad argument");
+    NSG_REQUIRE(C % 4 == 0 && C <= 1024 && nsg_aligned16(x) && rows_per_clip < (1ll << 31), NSG_E_UNSUPPORTED,
+                "nsg_clip_colsum: C must be a multiple of 4 (<= 1024), x 16-byte aligned");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_clip_colsum_workspace_bytes(B, C), NSG_E_WORKSPACE, "nsg_clip_colsum: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(clip_colsum_partial_kernel, dim3(B * CLIP_SLABS), dim3(256), 0, s, x, (int)rows_per_clip, C, CLIP_SLABS, partial);
+    hipLaunchKernelGGL(clip_colsum_final_kernel, dim3((unsigned)nsg_cdiv((int64_t)B * C, 256)), dim3(256), 0, s, partial, B, CLIP_SLABS, C, out);
+    return nsg_check_launch("clip_colsum");
 }
 
 size_t nsg_reduce_workspace_bytes(int64_t n)

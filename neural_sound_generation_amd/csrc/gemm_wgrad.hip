@@ -356,7 +356,8 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
 {
     const int ntaps = p.KH * p.KW;
     if (p.Mp <= 0) return nsg_fail(NSG_E_INVALID, "wgrad: empty reduction");
-    if (p.A % 4 != 0 || p.C % 4 != 0) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: channels (%d,%d) must be multiples of 4", p.A, p.C);
+    // one-hot rows are generated, not loaded: any number of codes works there
+    if ((!p.onehot && p.A % 4 != 0) || p.C % 4 != 0) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: channels (%d,%d) must be multiples of 4", p.A, p.C);
     if ((!p.onehot && !nsg_aligned16(p.P)) || !nsg_aligned16(p.Q)) return nsg_fail(NSG_E_INVALID, "wgrad: operands must be 16-byte aligned");
     const SlabPlan sp = plan_slabs(p.Mp, ntaps, p.A, p.C);
     const size_t need = (size_t)sp.nslab * ntaps * p.A * p.C * sizeof(float);

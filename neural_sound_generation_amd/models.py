@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import engine, functional as Fn, ops
-from .vector_quantization import vq, vq_st, codebook_lookup
+from .vector_quantization import vq, vq_st, codebook_lookup, add_per_clip
 
 
 def to_scalar(arr):
@@ -46,10 +46,21 @@ def weights_init(m):
 
 
 class VQEmbedding(nn.Module):
-    def __init__(self, z_dim, dim):
+    """Reference signature VQEmbedding(z_dim, dim) (models.py:121-125).  Extension (not in the
+    reference, opt-in): ema_decay=<float> switches the codebook from gradient training to the
+    exponential-moving-average update of the VQ-VAE paper (appendix A.1); the codebook then gets no
+    gradient and `FusedTrainStep` updates it from all-reduced per-code counts and sums."""
+
+    def __init__(self, z_dim, dim, ema_decay=None, ema_eps=1e-5):
         super().__init__()
         self.embedding = nn.Embedding(z_dim, dim)
         self.embedding.weight.data.uniform_(-1. / z_dim, 1. / z_dim)
+        self.ema_decay = ema_decay
+        self.ema_eps = ema_eps
+        if ema_decay is not None:
+            self.embedding.weight.requires_grad_(False)
+            self.register_buffer("ema_count", torch.zeros(z_dim))
+            self.register_buffer("ema_sum", self.embedding.weight.data.clone())
 
     def forward(self, z_e_x):
         z_e_x_ = Fn.to_nhwc(z_e_x)
@@ -94,7 +105,10 @@ class _Decoder(nn.Sequential):
 
 
 class VQVAE(nn.Module):
-    def __init__(self, input_dim, dim, z_dim=512):
+    def __init__(self, input_dim, dim, z_dim=512, ema_decay=None, n_speakers=None):
+        """Reference signature VQVAE(input_dim, dim, z_dim=512) (models.py:162).  Opt-in extensions,
+        neither present in the reference: ema_decay (EMA codebook) and
+        n_speakers (speaker embedding added to the decoder input, BASELINE configs[2])."""
         super().__init__()
         if input_dim != 1:
             raise NotImplementedError("the HIP path implements the speech configuration (input_dim == 1: "
@@ -107,7 +121,7 @@ class VQVAE(nn.Module):
             ResBlock(dim),
             ResBlock(dim),
         )
-        self.codebook = VQEmbedding(z_dim, dim)
+        self.codebook = VQEmbedding(z_dim, dim, ema_decay=ema_decay)
         self.decoder = _Decoder(
             ResBlock(dim),
             ResBlock(dim),
@@ -118,18 +132,29 @@ class VQVAE(nn.Module):
             nn.ConvTranspose2d(dim, input_dim, 4, 2, 1),
             nn.Tanh()
         )
+        self.n_speakers = n_speakers
+        if n_speakers is not None:
+            self.speaker_embedding = nn.Embedding(n_speakers, dim)
+            self.speaker_embedding.weight.data.normal_(0.0, 0.1)
         self.apply(weights_init)
+
+    def _condition(self, z_q_x, g):
+        """Add the speaker embedding of each clip to every latent pixel of that clip (extension)."""
+        if self.n_speakers is None or g is None:
+            return z_q_x
+        rows = codebook_lookup(self.speaker_embedding.weight, g.view(-1).to(torch.int64))
+        return Fn.to_nchw_view(add_per_clip(Fn.to_nhwc(z_q_x), rows))
 
     def encode(self, x):
         z_e_x = self.encoder(x)
         return self.codebook(z_e_x)
 
-    def decode(self, latents):
+    def decode(self, latents, g=None):
         z_q_x = Fn.to_nchw_view(ops.gather_rows(self.codebook.embedding.weight.detach().contiguous(), latents.contiguous()))
-        return self.decoder(z_q_x)
+        return self.decoder(self._condition(z_q_x, g))
 
-    def forward(self, x):
+    def forward(self, x, g=None):
         z_e_x = self.encoder(x)
         z_q_x_st, z_q_x = self.codebook.straight_through(z_e_x)
-        x_tilde = self.decoder(z_q_x_st)
+        x_tilde = self.decoder(self._condition(z_q_x_st, g))
         return x_tilde, z_e_x, z_q_x

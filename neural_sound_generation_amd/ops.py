@@ -311,6 +311,26 @@ def add(a, b, out=None):
     return y
 
 
+def add_per_clip(x, rows, out=None):
+    """x NHWC (B,H,W,C) + rows (B,C) broadcast over each clip's pixels."""
+    _chk(x, "x"); _chk(rows, "rows")
+    B, C = rows.shape
+    y = out if out is not None else torch.empty_like(x)
+    _lib.call("nsg_add_per_clip", _p(x), _p(rows), _p(y), c_int32(B), c_int64(x.numel() // (B * C)), c_int32(C), _stream())
+    return y
+
+
+def clip_colsum(x, B):
+    """x NHWC (B,H,W,C) -> (B,C): per-clip sum over pixels."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    nb = _lib.query("nsg_clip_colsum_workspace_bytes", c_int32(B), c_int32(C))
+    ws = WS.get(nb, x.device)
+    _lib.call("nsg_clip_colsum", _p(x), c_int32(B), c_int64(x.numel() // (B * C)), c_int32(C), _p(out), _p(ws), c_size_t(nb), _stream())
+    return out
+
+
 def mse_padded(a, c, rows, wa, wc, grad_scale=1.0, want_grad=True):
     """mean((pad(a) - c)^2) with a zero-padded from width wa to wc (train.py:118-129)."""
     loss = torch.empty(1, dtype=torch.float32, device=a.device)

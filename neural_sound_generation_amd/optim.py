@@ -16,7 +16,7 @@ _ALIGN = 64  # floats (256 bytes): keeps every view 16-byte aligned for the floa
 
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        params = list(params)
+        params = [p for p in params if p.requires_grad]   # e.g. an EMA-trained codebook takes no gradient step
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._params = [p for g in self.param_groups for p in g["params"]]
         if not self._params:

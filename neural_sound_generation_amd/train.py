@@ -32,17 +32,21 @@ class FusedTrainStep:
         self.world = nsg_dist.world_size(process_group)
         if self.world > 1:
             nsg_dist.broadcast_flat(self.opt.flat_param, 0, process_group)
+        self.ema = getattr(model.codebook, "ema_decay", None) is not None
         self.encP = engine.encoder_params(model.encoder)
         self.decP = engine.decoder_params(model.decoder)
         self.codebook = model.codebook.embedding.weight
         self.g_enc = self.opt.grads_for(engine.encoder_param_list(self.encP))
         self.g_dec = self.opt.grads_for(engine.decoder_param_list(self.decP))
-        self.g_code = self.opt.grads_for([self.codebook])[0]
+        self.g_code = None if self.ema else self.opt.grads_for([self.codebook])[0]
+        self.spk = getattr(model, "speaker_embedding", None)
+        self.g_spk = self.opt.grads_for([self.spk.weight])[0] if self.spk is not None else None
 
     @torch.no_grad()
-    def forward_backward(self, c: torch.Tensor):
-        """c: (B,1,80,T) float32 on the GPU.  Fills the flat gradient bucket; returns the three loss
-        tensors (device scalars; nothing here synchronises with the host)."""
+    def forward_backward(self, c: torch.Tensor, g: torch.Tensor | None = None):
+        """c: (B,1,80,T) float32 on the GPU; g: optional (B,) int64 speaker ids (speaker-conditioned
+        decoder extension).  Fills the flat gradient bucket; returns the three loss tensors (device
+        scalars; nothing here synchronises with the host)."""
         model = self.model
         if not model.training:
             raise RuntimeError("FusedTrainStep needs model.train()")
@@ -53,14 +57,31 @@ class FusedTrainStep:
         K = self.codebook.shape[0]
         idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True)
         zq = zq.view_as(ze)
-        xt, ds = engine.decoder_forward(zq, self.decP, True)
+        zdec = zq
+        if self.spk is not None and g is not None:
+            g = g.view(-1).to(torch.int64).contiguous()
+            zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g))
+        xt, ds = engine.decoder_forward(zdec, self.decP, True)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
         loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
         dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)
+        if self.spk is not None:
+            if g is not None:   # d loss / d speaker rows = per-clip pixel sums of dzq, scattered to the speakers
+                gs = ops.index_add_rows(g, ops.clip_colsum(dzq, B), self.spk.weight.shape[0])
+                ops.add(gs, None, out=self.g_spk)
+            else:
+                self.g_spk.zero_()
         # loss_vq = mse(z_q, sg(z_e)) -> codebook; loss_commit = mse(z_e, sg(z_q)) -> encoder,
         # plus the straight-through gradient from the decoder               (train.py:131-134)
-        loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq)
-        self._codebook_grad(idx, dq.view(-1, D), K)
+        if self.ema:
+            # EMA codebook (extension): no codebook gradient; per-code counts and sums of the assigned
+            # encoder rows are the statistics every rank contributes (summed over ranks in step())
+            loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False)
+            s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True)
+            self.ema_stats = torch.cat([n, s.view(-1)])       # ONE buffer -> ONE small all-reduce
+        else:
+            loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq)
+            self._codebook_grad(idx, dq.view(-1, D), K)
         engine.encoder_backward(dz, es, self.encP, gout=self.g_enc)
         self.last_indices = idx
         return loss_recons, loss_vq, loss_vq
@@ -70,12 +91,24 @@ class FusedTrainStep:
         ops.add(g, None, out=self.g_code)
 
     @torch.no_grad()
-    def step(self, c: torch.Tensor):
-        losses = self.forward_backward(c)
+    def step(self, c: torch.Tensor, g: torch.Tensor | None = None):
+        losses = self.forward_backward(c, g)
         if self.world > 1:
             nsg_dist.allreduce_sum_(self.opt.flat_grad, self.group)
+            if self.ema:
+                nsg_dist.allreduce_sum_(self.ema_stats, self.group)
         self.opt.step(grad_scale=1.0 / self.world)
+        if self.ema:
+            self.apply_ema(self.ema_stats)
         return losses
+
+    @torch.no_grad()
+    def apply_ema(self, stats: torch.Tensor):
+        """stats = [n (K) | s (K*D)] summed over ranks: identical update on every rank."""
+        cb = self.model.codebook
+        K, D = self.codebook.shape
+        ops.vq_ema_update(self.codebook.data, cb.ema_count, cb.ema_sum, stats[:K].contiguous(), stats[K:].view(K, D).contiguous(),
+                          decay=cb.ema_decay, eps=cb.ema_eps)
 
 
 def vqvae_loss_terms(c, x_tilde, z_e_x, z_q_x):

@@ -77,7 +77,24 @@ class CodebookLookup(Function):
         return ops.index_add_rows(indices.view(-1), g, ctx.codebook_rows), None
 
 
+class AddPerClip(Function):
+    """z (B,H,W,D) + rows (B,D) broadcast over pixels -- the speaker-conditioning add (extension)."""
+
+    @staticmethod
+    def forward(ctx, z, rows):
+        ctx.batch = rows.shape[0]
+        return ops.add_per_clip(z.detach().contiguous(), rows.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gz = ops.add(g, None) if ctx.needs_input_grad[0] else None
+        gr = ops.clip_colsum(g, ctx.batch) if ctx.needs_input_grad[1] else None
+        return gz, gr
+
+
 vq = VectorQuantization.apply
+add_per_clip = AddPerClip.apply
 vq_st = VectorQuantizationStraightThrough.apply
 codebook_lookup = CodebookLookup.apply
 __all__ = ["vq", "vq_st", "codebook_lookup"]

@@ -287,6 +287,79 @@ def test_full_width_step_against_oracle(dim, z_dim, B, T, fused_stats):
             assert err_gpu <= 4.0 * err_cpu + 1e-4, f"{k}: GPU {err_gpu:.2e} vs CPU-fp32 {err_cpu:.2e} (relative L2 distance to the fp64 result)"
 
 
+def test_ema_codebook_mode_and_data_parallel_identity():
+    """EMA codebook (extension; no reference semantics -> parity unpinned, pinned to the oracle's
+    restatement of the VQ-VAE paper's update).  Also the DP identity of SURVEY.md section 8e: the
+    statistics summed over two shards, applied once, equal what each rank would apply after the
+    all-reduce; counts are exact integers."""
+    torch.manual_seed(1)
+    K, D = 32, 16
+    model = M.VQVAE(1, D, K, ema_decay=0.99).to(DEV).train()
+    assert not model.codebook.embedding.weight.requires_grad
+    assert "codebook.ema_count" in model.state_dict() and "codebook.ema_sum" in model.state_dict()
+    c = torch.rand(4, 1, 80, 32, generator=torch.Generator().manual_seed(5)).to(DEV)
+    step = FusedTrainStep(model, lr=1e-3)
+    w0 = model.codebook.embedding.weight.detach().clone()
+    n0, s0 = model.codebook.ema_count.clone(), model.codebook.ema_sum.clone()
+    step.forward_backward(c)
+    stats = step.ema_stats.clone()
+    idx = step.last_indices.cpu()
+    # statistics against torch on the same encoder output
+    ze = model.encoder(c).detach()
+    zflat = ze.permute(0, 2, 3, 1).reshape(-1, D).cpu()
+    n_ref, s_ref = O.ema_stats(zflat, idx, K)
+    assert torch.equal(stats[:K].cpu(), n_ref)
+    np.testing.assert_allclose(stats[K:].view(K, D).cpu().numpy(), s_ref.numpy(), rtol=1e-5, atol=1e-5)
+    w_ref, n1_ref, s1_ref = O.ema_update(w0.cpu(), n0.cpu(), s0.cpu(), n_ref, s_ref, decay=0.99)
+    step.apply_ema(stats)
+    np.testing.assert_allclose(model.codebook.embedding.weight.detach().cpu().numpy(), w_ref.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(model.codebook.ema_count.cpu().numpy(), n1_ref.numpy(), rtol=1e-6)
+    # data-parallel identity: two half-batches -> summed statistics == full-batch statistics (given the same z_e)
+    h = zflat.shape[0] // 2
+    s_a, n_a = ops.index_add_rows(idx[:h].to(DEV), zflat[:h].to(DEV).contiguous(), K, want_counts=True)
+    s_b, n_b = ops.index_add_rows(idx[h:].to(DEV), zflat[h:].to(DEV).contiguous(), K, want_counts=True)
+    assert torch.equal((n_a + n_b).cpu(), n_ref)
+    np.testing.assert_allclose((s_a + s_b).cpu().numpy(), s_ref.numpy(), rtol=1e-5, atol=1e-5)
+    # a full fused step runs and moves the codebook without touching it through Adam
+    before = model.codebook.embedding.weight.detach().clone()
+    step.step(c)
+    assert not torch.equal(before, model.codebook.embedding.weight.detach())
+
+
+def test_speaker_conditioned_decoder():
+    """Speaker embedding added to the decoder input (extension, BASELINE configs[2]; parity unpinned: the
+    reference ignores g).  Checked against CPU autograd of the same definition, and fused == autograd."""
+    torch.manual_seed(1)
+    D, K, S = 16, 32, 7
+    model = M.VQVAE(1, D, K, n_speakers=S)
+    st0 = {k: v.clone() for k, v in model.state_dict().items()}
+    c = torch.rand(4, 1, 80, 32, generator=torch.Generator().manual_seed(7))
+    g = torch.tensor([3, 0, 3, 6])
+    # CPU definition: oracle encoder / quantiser / decoder with the embedding rows added per clip
+    ost = O.clone_state({k: v for k, v in st0.items() if not k.startswith("speaker_embedding")})
+    emb = st0["speaker_embedding.weight"].clone().requires_grad_(True)
+    z_e = O.encoder(c, ost, True, {})
+    zq_st, zq_bar, idx = O.straight_through(z_e, ost["codebook.embedding.weight"])
+    x_t = O.decoder(zq_st + emb[g][:, :, None, None], ost, True, {})
+    lr_, lv, lc = O.loss_terms(c, x_t, z_e, zq_bar)
+    (gemb,) = torch.autograd.grad(lr_ + lv + lc, [emb])
+    model = model.to(DEV).train()
+    step = FusedTrainStep(model, lr=1e-3)
+    l = step.forward_backward(c.to(DEV), g.to(DEV))
+    assert rel(l[0].item(), lr_.item()) < LOSS_RTOL
+    got = model.speaker_embedding.weight.grad.cpu()
+    assert float(got[1].abs().max()) == 0.0                      # speakers absent from the batch get no gradient
+    np.testing.assert_allclose(got.numpy(), gemb.numpy(), rtol=2e-4, atol=2e-4 * float(gemb.abs().max()))
+    # autograd path gives the same gradient
+    m2 = M.VQVAE(1, D, K, n_speakers=S)
+    m2.load_state_dict(st0)
+    m2 = m2.to(DEV).train()
+    xt, ze, zq = m2(c.to(DEV), g.to(DEV))
+    l3 = vqvae_loss_terms(c.to(DEV), xt, ze, zq)
+    (l3[0] + l3[1] + l3[2]).backward()
+    np.testing.assert_allclose(m2.speaker_embedding.weight.grad.cpu().numpy(), got.numpy(), rtol=1e-4, atol=1e-5 * float(got.abs().max()) + 1e-9)
+
+
 def test_module_surface_on_gpu():
     torch.manual_seed(1)
     m = M.VQVAE(1, 16, 32).to(DEV)

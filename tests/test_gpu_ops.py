@@ -131,7 +131,7 @@ def test_vq_operator_surface(golden_dir):
     np.testing.assert_allclose(e2.grad.cpu().numpy(), g["st.ge"], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("N,D,K", [(300, 16, 24), (5000, 64, 128), (20000, 128, 512), (3000, 256, 1000)])
+@pytest.mark.parametrize("N,D,K", [(300, 16, 24), (5000, 64, 128), (20000, 128, 512), (3000, 256, 1000), (4, 16, 7), (1000, 32, 101)])
 def test_index_add_rows_and_counts(N, D, K):
     g = torch.Generator().manual_seed(N)
     idx = torch.randint(0, K, (N,), generator=g)
