@@ -47,11 +47,16 @@ enum {
     NSG_E_WORKSPACE = -3    /* workspace too small */
 };
 
+/* storage type of activations / packed weights: fp32 is the parity mode, bf16 (fp32 accumulate,
+ * fp32 BatchNorm statistics, fp32 VQ) the throughput mode */
+enum { NSG_F32 = 0, NSG_BF16 = 1 };
+
 /* flags shared by the convolution entry points */
 enum {
     NSG_RELU_IN = 1,   /* apply max(0,.) to the (gathered) input operand while loading it          */
     NSG_TANH_OUT = 2,  /* apply tanh to the result (forward only)                                   */
-    NSG_RELU_IN2 = 4   /* wgrad only: apply max(0,.) to the output-side operand (see nsg_conv_wgrad) */
+    NSG_RELU_IN2 = 4,  /* wgrad only: apply max(0,.) to the output-side operand (see nsg_conv_wgrad) */
+    NSG_OUT_F32 = 8    /* forward only: write y as fp32 even when the layer's dtype is bf16          */
 };
 
 /* Geometry of one convolution layer.  transposed = 0: nn.Conv2d(C_in, C_out, k, stride, pad);
@@ -65,6 +70,10 @@ typedef struct nsg_conv_desc {
     int32_t OH, OW, C_out;
     int32_t k, stride, pad;
     int32_t transposed;
+    int32_t dtype; /* NSG_F32 / NSG_BF16: storage type of the multi-channel activations and of the packed
+                      weights.  Single-channel tensors (C == 1: the mel image, the reconstruction and their
+                      gradients), biases, weight gradients and the reference-layout weights are always fp32.
+                      bf16 needs channel counts that are multiples of 8. */
 } nsg_conv_desc;
 
 NSG_API int nsg_version(void);
@@ -120,12 +129,12 @@ NSG_API int nsg_vq_ema_update(float *e, float *ema_n, float *ema_s, const float 
  * Convolutions                                            src/models.py:150,153,165,168,179,182
  * ------------------------------------------------------------------------------------------- */
 
-/* Floats in each packed weight image (forward image, dgrad image). */
+/* ELEMENTS (of d->dtype) in each packed weight image (forward image, dgrad image). */
 NSG_API size_t nsg_packed_weight_floats(const nsg_conv_desc *d);
 
 /* Re-pack reference-layout weights into the two [tap][n][c] images the GEMM kernels stream:
  * w_fwd for nsg_conv_forward, w_dgrad for nsg_conv_dgrad (either may be NULL to skip it). */
-NSG_API int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, float *w_fwd, float *w_dgrad, void *stream);
+NSG_API int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, void *w_fwd, void *w_dgrad, void *stream);
 
 /* Workspace bytes for forward/dgrad (C == 1 layers stage im2col/col2im images) and wgrad (split-K slabs). */
 NSG_API size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d);
@@ -133,7 +142,7 @@ NSG_API size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d);
 /* y = conv(x) + bias.  Replaces F.conv2d / F.conv_transpose2d as called by nn.Conv2d /
  * nn.ConvTranspose2d.forward at src/models.py:150,153,165,168,179,182.
  * flags: NSG_RELU_IN (the preceding nn.ReLU fused into the load), NSG_TANH_OUT (models.py:183). */
-NSG_API int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y,
+NSG_API int nsg_conv_forward(const nsg_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                              int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* nsg_conv_forward plus the training-mode BatchNorm statistics of its output y in the same pass:
@@ -141,18 +150,18 @@ NSG_API int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float
  * 153-154, 179-180).  The conv epilogue reduces each 128-row output tile to (count, mean, M2) while
  * the tile is still in LDS; the tiles are merged exactly as nsg_bn_stats merges its slabs.
  * mean/invstd/running_* as in nsg_bn_stats.  NSG_TANH_OUT is not allowed here. */
-NSG_API int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias,
-                                     float *y, int32_t flags, float eps, float momentum, float *mean, float *invstd,
+NSG_API int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, const void *w_fwd, const float *bias,
+                                     void *y, int32_t flags, float eps, float momentum, float *mean, float *invstd,
                                      float *running_mean, float *running_var, void *workspace, size_t workspace_bytes,
                                      void *stream);
 
 /* dx = d loss / d x given dy (autograd of the calls above).  flags: none. */
-NSG_API int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad, float *dx, int32_t flags,
+NSG_API int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* dw (reference weight layout, fully overwritten) and dbias (or NULL) given x and dy.
  * flags: NSG_RELU_IN treats x as max(0,x) (the fused preceding ReLU).  Deterministic. */
-NSG_API int nsg_conv_wgrad(const nsg_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
+NSG_API int nsg_conv_wgrad(const nsg_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,
                            int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -10,20 +10,22 @@ extern "C" NSG_API void nsg_debug_set_stamp_buffer(unsigned long long *buf) { g_
 namespace {
 
 // dst[(t*NN + n)*CC + c] = src[n*sn + c*sc + (flip ? T-1-t : t)]
-__global__ void pack_w_kernel(const float *__restrict__ src, float *__restrict__ dst, int T, int NN, int CC, int sn, int sc, int flip)
+template <typename TO>
+__global__ void pack_w_kernel(const float *__restrict__ src, TO *__restrict__ dst, int T, int NN, int CC, int sn, int sc, int flip)
 {
     const int64_t total = (int64_t)T * NN * CC;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % CC);
         const int n = (int)((i / CC) % NN);
         const int t = (int)(i / ((int64_t)CC * NN));
-        dst[i] = src[(size_t)n * sn + (size_t)c * sc + (flip ? T - 1 - t : t)];
+        Elem<TO>::put(dst + i, src[(size_t)n * sn + (size_t)c * sc + (flip ? T - 1 - t : t)]);
     }
 }
 
 // img [B][HH][WW] (one channel) -> patches [B][LH][LW][16], tap = kh*4+kw, pixel (2ly+kh-1, 2lx+kw-1)
 // (LH,LW) = floor(HH/2), floor(WW/2): the 4/2/1 convolution's output grid
-__global__ void im2col_c1_kernel(const float *__restrict__ img, float *__restrict__ patches, int B, int LH, int LW, int HH, int WW)
+template <typename TO>
+__global__ void im2col_c1_kernel(const float *__restrict__ img, TO *__restrict__ patches, int B, int LH, int LW, int HH, int WW)
 {
     const int64_t total = (int64_t)B * LH * LW * 4;  // one thread per (pixel, kh)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -42,7 +44,13 @@ __global__ void im2col_c1_kernel(const float *__restrict__ img, float *__restric
             if (x0 + 2 < WW) v.z = row[x0 + 2];
             if (x0 + 3 < WW) v.w = row[x0 + 3];
         }
-        *reinterpret_cast<v4f *>(patches + i * 4) = v;
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<v4f *>(patches + i * 4) = v;
+        } else {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            v2u pk = {(unsigned)nsg_f2bf(v.x) | ((unsigned)nsg_f2bf(v.y) << 16), (unsigned)nsg_f2bf(v.z) | ((unsigned)nsg_f2bf(v.w) << 16)};
+            *reinterpret_cast<v2u *>(patches + i * 4) = pk;
+        }
     }
 }
 
@@ -77,7 +85,8 @@ __global__ void col2im_c1_kernel(const float *__restrict__ dots, const float *__
 
 // column sums of [M][C] in two deterministic stages
 constexpr int CS_MAX_SLABS = 512;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, int64_t M, int C, int slab_rows,
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const TI *__restrict__ x, int64_t M, int C, int slab_rows,
                                                              float *__restrict__ partial)
 {
     __shared__ float red[256];
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
         const int c = cb + cl;
         float s = 0.f;
         if (rg < rgroups && c < C)
-            for (int64_t r = r0 + rg; r < r1; r += rgroups) s += x[r * C + c];
+            for (int64_t r = r0 + rg; r < r1; r += rgroups) s += Elem<TI>::get(x + r * C + c);
         red[tid] = (rg < rgroups) ? s : 0.f;
         __syncthreads();
         if (tid < Cb && cb + tid < C) {
@@ -161,14 +170,16 @@ inline CsGeom cs_geom(int64_t M)
 }
 inline size_t colsum_ws_bytes(int64_t M, int C) { return nsg_align_up((size_t)cs_geom(M).nslab * C * sizeof(float), 256); }
 
-int colsum(const float *x, int64_t M, int C, float *out, void *ws, hipStream_t s)
+int colsum(const void *x, int dtype, int64_t M, int C, float *out, void *ws, hipStream_t s)
 {
     const CsGeom g = cs_geom(M);
     float *partial = reinterpret_cast<float *>(ws);
-    if (C % 4 == 0 && nsg_aligned16(x))
-        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
+    if (dtype == NSG_BF16)
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), M, C, g.rows, partial);
+    else if (C % 4 == 0 && nsg_aligned16(x))
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const float *>(x), M, C, g.rows, partial);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(g.nslab), dim3(256), 0, s, x, M, C, g.rows, partial);
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const float *>(x), M, C, g.rows, partial);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, out);
     return nsg_check_launch("colsum");
 }
@@ -189,6 +200,8 @@ int classify(const nsg_conv_desc *d, const char *fn)
     if (!d) return nsg_fail(NSG_E_INVALID, "%s: null descriptor", fn);
     if (d->B <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->C_in <= 0 || d->C_out <= 0 || d->k <= 0)
         return nsg_fail(NSG_E_INVALID, "%s: non-positive geometry", fn);
+    if (d->dtype != NSG_F32 && d->dtype != NSG_BF16) return nsg_fail(NSG_E_INVALID, "%s: unknown dtype %d", fn, d->dtype);
+    const int cm = d->dtype == NSG_BF16 ? 8 : 4;   // channel granularity of the 16-byte accesses
     const int64_t nin = (int64_t)d->B * d->IH * d->IW * d->C_in, nout = (int64_t)d->B * d->OH * d->OW * d->C_out;
     if (nin >= (1ll << 31) || nout >= (1ll << 31)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: tensor with >= 2^31 elements", fn);
     if (!d->transposed) {
@@ -197,11 +210,11 @@ int classify(const nsg_conv_desc *d, const char *fn)
         if (d->OH != (d->IH + 2 * d->pad - d->k) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - d->k) / d->stride + 1)
             return nsg_fail(NSG_E_INVALID, "%s: output extent does not match Conv2d geometry", fn);
         if (d->C_in == 1) {
-            if (!(d->k == 4 && d->stride == 2 && d->pad == 1 && d->C_out % 4 == 0))
-                return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in=1 needs k=4,stride=2,pad=1 and C_out%%4==0", fn);
+            if (!(d->k == 4 && d->stride == 2 && d->pad == 1 && d->C_out % cm == 0))
+                return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in=1 needs k=4,stride=2,pad=1 and C_out%%%d==0", fn, cm);
             return K_CONV_C1;
         }
-        if (d->C_in % 4 || d->C_out % 4) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of 4", fn);
+        if (d->C_in % cm || d->C_out % cm) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of %d", fn, cm);
         if (d->stride == 2 && !(d->k == 4 && d->pad == 1))
             return nsg_fail(NSG_E_UNSUPPORTED, "%s: stride-2 Conv2d needs k=4,pad=1", fn);
         return K_CONV;
@@ -209,17 +222,19 @@ int classify(const nsg_conv_desc *d, const char *fn)
     if (!(d->k == 4 && d->stride == 2 && d->pad == 1)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: ConvTranspose2d needs k=4,stride=2,pad=1", fn);
     if (d->OH != 2 * d->IH || d->OW != 2 * d->IW) return nsg_fail(NSG_E_INVALID, "%s: output extent does not match ConvTranspose2d geometry", fn);
     if (d->C_out == 1) {
-        if (d->C_in % 4) return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in must be a multiple of 4", fn);
+        if (d->C_in % cm) return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in must be a multiple of %d", fn, cm);
         return K_CONVT_C1;
     }
-    if (d->C_in % 4 || d->C_out % 4) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of 4", fn);
+    if (d->C_in % cm || d->C_out % cm) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of %d", fn, cm);
     return K_CONVT;
 }
 
+inline size_t esize(const nsg_conv_desc *d) { return d->dtype == NSG_BF16 ? 2 : 4; }
 inline int64_t lowres_pixels(const nsg_conv_desc *d)
 {
     return d->transposed ? (int64_t)d->B * d->IH * d->IW : (int64_t)d->B * d->OH * d->OW;
 }
+// staging image of the single-channel layers: [low-res pixels][16]: patches (dtype) or tap products (fp32)
 inline size_t patches_bytes(const nsg_conv_desc *d) { return nsg_align_up((size_t)lowres_pixels(d) * 16 * sizeof(float), 256); }
 
 // per-row-tile BatchNorm statistics written by the conv epilogue: [tiles][3][C_out]
@@ -230,16 +245,27 @@ inline size_t stats_tiles_bytes(const nsg_conv_desc *d)
     return nsg_align_up((size_t)(tiles + 8) * 3 * d->C_out * sizeof(float), 256);
 }
 
-GatherGemmParams gg_1x1(const float *in, const float *w, const float *bias, float *out, int64_t M, int CI, int CO, int flags)
+GatherGemmParams gg_1x1(const void *in, const void *w, const float *bias, void *out, int64_t M, int CI, int CO, int flags, int in_dtype,
+                        int out_dtype)
 {
     GatherGemmParams p = {};
     p.in = in; p.w = w; p.bias = bias; p.out = out;
+    p.in_dtype = in_dtype; p.out_dtype = out_dtype;
     p.B = 1; p.IH = 1; p.IW = (int)M; p.CI = CI;
     p.OH = 1; p.OW = (int)M; p.CO = CO;
     p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.mode = 0; p.M = (int)M; p.RH = 1; p.RW = (int)M;
     p.flags = flags;
     return p;
+}
+
+void launch_im2col(const nsg_conv_desc *d, const float *img, void *patches, int LH, int LW, int HH, int WW, hipStream_t s)
+{
+    const int64_t n = (int64_t)d->B * LH * LW * 4;
+    if (d->dtype == NSG_BF16)
+        hipLaunchKernelGGL((im2col_c1_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, s, img, reinterpret_cast<bf16_t *>(patches), d->B, LH, LW, HH, WW);
+    else
+        hipLaunchKernelGGL((im2col_c1_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, s, img, reinterpret_cast<float *>(patches), d->B, LH, LW, HH, WW);
 }
 
 }  // namespace
@@ -252,7 +278,7 @@ size_t nsg_packed_weight_floats(const nsg_conv_desc *d)
     return (size_t)d->k * d->k * d->C_in * d->C_out;
 }
 
-int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, float *w_fwd, float *w_dgrad, void *stream)
+int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, void *w_fwd, void *w_dgrad, void *stream)
 {
     const int kind = classify(d, "nsg_pack_conv_weights");
     if (kind < 0) return kind;
@@ -260,8 +286,10 @@ int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, float *w_fwd, 
     hipStream_t s = (hipStream_t)stream;
     const int T = d->k * d->k, CI = d->C_in, CO = d->C_out;
     const int nb = ew_blocks((int64_t)T * CI * CO);
-    auto pack = [&](float *dst, int TT, int NN, int CC, int sn, int sc, int flip) {
-        hipLaunchKernelGGL(pack_w_kernel, dim3(nb), dim3(256), 0, s, w, dst, TT, NN, CC, sn, sc, flip);
+    const bool bf = d->dtype == NSG_BF16;
+    auto pack = [&](void *dst, int TT, int NN, int CC, int sn, int sc, int flip) {
+        if (bf) hipLaunchKernelGGL((pack_w_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, w, reinterpret_cast<bf16_t *>(dst), TT, NN, CC, sn, sc, flip);
+        else    hipLaunchKernelGGL((pack_w_kernel<float>), dim3(nb), dim3(256), 0, s, w, reinterpret_cast<float *>(dst), TT, NN, CC, sn, sc, flip);
     };
     switch (kind) {
     case K_CONV:  // w[co][ci][t]
@@ -303,16 +331,18 @@ size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d)
     return bytes;
 }
 
-static int conv_forward_impl(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y, int32_t flags,
+static int conv_forward_impl(const nsg_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, int32_t flags,
                              void *workspace, size_t workspace_bytes, void *stream, float *stats, int *stats_tiles)
 {
     const int kind = classify(d, "nsg_conv_forward");
     if (kind < 0) return kind;
     NSG_REQUIRE(x && w_fwd && y, NSG_E_INVALID, "nsg_conv_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    const int out_dtype = (flags & NSG_OUT_F32) ? NSG_F32 : d->dtype;
     if (kind == K_CONV || kind == K_CONVT) {
         GatherGemmParams p = {};
         p.in = x; p.w = w_fwd; p.bias = bias; p.out = y;
+        p.in_dtype = d->dtype; p.out_dtype = out_dtype;
         p.B = d->B; p.IH = d->IH; p.IW = d->IW; p.CI = d->C_in;
         p.OH = d->OH; p.OW = d->OW; p.CO = d->C_out;
         p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
@@ -326,34 +356,34 @@ static int conv_forward_impl(const nsg_conv_desc *d, const float *x, const float
         return nsg_launch_gather_gemm(p, s);
     }
     NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward: workspace too small");
-    float *stage = reinterpret_cast<float *>(workspace);
     const int64_t Mp = lowres_pixels(d);
-    if (kind == K_CONV_C1) {
+    if (kind == K_CONV_C1) {   // x is the fp32 single-channel image
         NSG_REQUIRE(!(flags & NSG_RELU_IN), NSG_E_UNSUPPORTED, "nsg_conv_forward: NSG_RELU_IN on a single-channel input");
-        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, x, stage, d->B, d->OH, d->OW, d->IH, d->IW);
+        launch_im2col(d, reinterpret_cast<const float *>(x), workspace, d->OH, d->OW, d->IH, d->IW, s);
         int rc = nsg_check_launch("im2col_c1_kernel");
         if (rc) return rc;
-        GatherGemmParams p1 = gg_1x1(stage, w_fwd, bias, y, Mp, 16, d->C_out, flags & NSG_TANH_OUT);
+        GatherGemmParams p1 = gg_1x1(workspace, w_fwd, bias, y, Mp, 16, d->C_out, flags & NSG_TANH_OUT, d->dtype, out_dtype);
         p1.stats = stats;
         if (stats_tiles) *stats_tiles = nsg_gather_gemm_row_tiles(p1);
         return nsg_launch_gather_gemm(p1, s);
     }
     NSG_REQUIRE(stats == nullptr, NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: not available for a single-channel output");
-    // K_CONVT_C1: per-input-pixel tap products, then the 4-tap gather with bias (+tanh)
-    int rc = nsg_launch_gather_gemm(gg_1x1(x, w_fwd, nullptr, stage, Mp, d->C_in, 16, flags & NSG_RELU_IN), s);
+    // K_CONVT_C1: per-input-pixel tap products (fp32), then the 4-tap gather with bias (+tanh) into the fp32 image y
+    float *dots = reinterpret_cast<float *>(workspace);
+    int rc = nsg_launch_gather_gemm(gg_1x1(x, w_fwd, nullptr, dots, Mp, d->C_in, 16, flags & NSG_RELU_IN, d->dtype, NSG_F32), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->OH * d->OW)), dim3(256), 0, s, stage, bias, y, d->B,
-                       d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0);
+    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->OH * d->OW)), dim3(256), 0, s, dots, bias,
+                       reinterpret_cast<float *>(y), d->B, d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0);
     return nsg_check_launch("col2im_c1_kernel");
 }
 
-int nsg_conv_forward(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y, int32_t flags,
+int nsg_conv_forward(const nsg_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y, int32_t flags,
                      void *workspace, size_t workspace_bytes, void *stream)
 {
     return conv_forward_impl(d, x, w_fwd, bias, y, flags, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
-int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const float *x, const float *w_fwd, const float *bias, float *y,
+int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                              int32_t flags, float eps, float momentum, float *mean, float *invstd, float *running_mean,
                              float *running_var, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -372,7 +402,7 @@ int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const float *x, const float
                                    (hipStream_t)stream);
 }
 
-int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad, float *dx, int32_t flags, void *workspace,
+int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, int32_t flags, void *workspace,
                    size_t workspace_bytes, void *stream)
 {
     (void)flags;
@@ -384,6 +414,7 @@ int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad
         // roles swap: the gradient of a conv is a transposed conv and vice versa
         GatherGemmParams p = {};
         p.in = dy; p.w = w_dgrad; p.bias = nullptr; p.out = dx;
+        p.in_dtype = d->dtype; p.out_dtype = d->dtype;
         p.B = d->B; p.IH = d->OH; p.IW = d->OW; p.CI = d->C_out;
         p.OH = d->IH; p.OW = d->IW; p.CO = d->C_in;
         p.KH = d->k; p.KW = d->k;
@@ -396,27 +427,28 @@ int nsg_conv_dgrad(const nsg_conv_desc *d, const float *dy, const float *w_dgrad
             p.mode = 0; p.stride = 2; p.pad = 1; p.RH = d->IH; p.RW = d->IW;  // gradient of convT = strided conv
         }
         p.M = d->B * p.RH * p.RW;
+        p.stamps = g_debug_stamps;
         return nsg_launch_gather_gemm(p, s);
     }
     NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_dgrad: workspace too small");
-    float *stage = reinterpret_cast<float *>(workspace);
     const int64_t Mp = lowres_pixels(d);
     if (kind == K_CONVT_C1) {
-        // dx[pix][ci] = sum_t patch(dy)[pix][t] * w[ci][t]
-        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, dy, stage, d->B, d->IH, d->IW, d->OH, d->OW);
+        // dy is the fp32 image: dx[pix][ci] = sum_t patch(dy)[pix][t] * w[ci][t]
+        launch_im2col(d, reinterpret_cast<const float *>(dy), workspace, d->IH, d->IW, d->OH, d->OW, s);
         int rc = nsg_check_launch("im2col_c1_kernel");
         if (rc) return rc;
-        return nsg_launch_gather_gemm(gg_1x1(stage, w_dgrad, nullptr, dx, Mp, 16, d->C_in, 0), s);
+        return nsg_launch_gather_gemm(gg_1x1(workspace, w_dgrad, nullptr, dx, Mp, 16, d->C_in, 0, d->dtype, d->dtype), s);
     }
-    // K_CONV_C1: dots[pix][t] = sum_co dy[pix][co] * w[co][t], scattered back onto the image
-    int rc = nsg_launch_gather_gemm(gg_1x1(dy, w_dgrad, nullptr, stage, Mp, d->C_out, 16, 0), s);
+    // K_CONV_C1: dots[pix][t] = sum_co dy[pix][co] * w[co][t] (fp32), scattered back onto the fp32 image dx
+    float *dots = reinterpret_cast<float *>(workspace);
+    int rc = nsg_launch_gather_gemm(gg_1x1(dy, w_dgrad, nullptr, dots, Mp, d->C_out, 16, 0, d->dtype, NSG_F32), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->IH * d->IW)), dim3(256), 0, s, stage, nullptr, dx, d->B,
-                       d->OH, d->OW, d->IH, d->IW, 0);
+    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->IH * d->IW)), dim3(256), 0, s, dots, nullptr,
+                       reinterpret_cast<float *>(dx), d->B, d->OH, d->OW, d->IH, d->IW, 0);
     return nsg_check_launch("col2im_c1_kernel");
 }
 
-int nsg_conv_wgrad(const nsg_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int32_t flags,
+int nsg_conv_wgrad(const nsg_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias, int32_t flags,
                    void *workspace, size_t workspace_bytes, void *stream)
 {
     const int kind = classify(d, "nsg_conv_wgrad");
@@ -428,15 +460,17 @@ int nsg_conv_wgrad(const nsg_conv_desc *d, const float *x, const float *dy, floa
     const int64_t Mp = lowres_pixels(d);
     const int relu_x = (flags & NSG_RELU_IN) ? 1 : 0;
     WgradParams p = {};
+    p.dtype = d->dtype;
     p.B = d->B; p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
     p.Mp = (int)Mp;
-    float *stage = nullptr;
+    void *stage = nullptr;
     if (kind == K_CONV_C1 || kind == K_CONVT_C1) {
-        stage = reinterpret_cast<float *>(ws);
+        stage = ws;
         ws += patches_bytes(d);
         p.B = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
         p.PH = 1; p.PW = (int)Mp; p.QH = 1; p.QW = (int)Mp; p.C = 16;
     }
+    int dy_dtype = d->dtype;   // storage type of dy for the bias gradient
     switch (kind) {
     case K_CONV:
         p.P = dy; p.PH = d->OH; p.PW = d->OW; p.A = d->C_out;
@@ -446,21 +480,22 @@ int nsg_conv_wgrad(const nsg_conv_desc *d, const float *x, const float *dy, floa
         p.P = x; p.PH = d->IH; p.PW = d->IW; p.A = d->C_in; p.relu_p = relu_x;
         p.Q = dy; p.QH = d->OH; p.QW = d->OW; p.C = d->C_out;
         break;
-    case K_CONV_C1:
+    case K_CONV_C1:   // x is the fp32 image
         NSG_REQUIRE(!relu_x, NSG_E_UNSUPPORTED, "nsg_conv_wgrad: NSG_RELU_IN on a single-channel input");
-        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, x, stage, d->B, d->OH, d->OW, d->IH, d->IW);
+        launch_im2col(d, reinterpret_cast<const float *>(x), stage, d->OH, d->OW, d->IH, d->IW, s);
         p.P = dy; p.A = d->C_out; p.Q = stage;
         break;
-    case K_CONVT_C1:
-        hipLaunchKernelGGL(im2col_c1_kernel, dim3(ew_blocks(Mp * 4)), dim3(256), 0, s, dy, stage, d->B, d->IH, d->IW, d->OH, d->OW);
+    case K_CONVT_C1:  // dy is the fp32 image
+        launch_im2col(d, reinterpret_cast<const float *>(dy), stage, d->IH, d->IW, d->OH, d->OW, s);
         p.P = x; p.A = d->C_in; p.relu_p = relu_x; p.Q = stage;
+        dy_dtype = NSG_F32;
         break;
     }
     const size_t wg_bytes = nsg_align_up(nsg_wgrad_workspace_bytes(Mp, p.KH * p.KW, p.A, p.C), 256);
     int rc = nsg_launch_wgrad(p, dw, ws, wg_bytes, s);
     if (rc) return rc;
     ws += wg_bytes;
-    if (dbias) return colsum(dy, (int64_t)d->B * d->OH * d->OW, d->C_out, dbias, ws, s);
+    if (dbias) return colsum(dy, dy_dtype, (int64_t)d->B * d->OH * d->OW, d->C_out, dbias, ws, s);
     return NSG_OK;
 }
 

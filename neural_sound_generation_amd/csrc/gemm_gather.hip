@@ -1,4 +1,8 @@
-// Implicit-GEMM convolution forward / data-gradient on v_mfma_f32_32x32x2_f32 (gfx950).
+// Implicit-GEMM convolution forward / data-gradient on the gfx950 matrix cores:
+//   fp32 operands -> v_mfma_f32_32x32x2_f32 (exact fp32, the parity mode)
+//   bf16 operands -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate, the throughput mode).
+// A K-chunk is 128 BYTES of one tap's channels in both modes (32 floats or 64 bf16), so staging, the LDS
+// image and the ds_read_b128 pattern are byte-identical; one ds_read_b128 feeds four 32x32x2 MFMAs or one 32x32x16.
 //
 //   out[pixel(m)][n] = bias[n] + sum over taps t, channels c of  in[pixel(m) shifted by tap t][c] * w[slice(t)][n][c]
 //
@@ -31,9 +35,15 @@ namespace {
 
 constexpr int LDS_PITCH = 36;   // floats per staged row (32 + 4 pad)
 
-template <int WM, int WN, int TM, int TN, int MODE, bool RELU>
-__global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
+template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams p)
 {
+    constexpr int EPV = 16 / (int)sizeof(TI);   // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
+    constexpr int KC = 8 * EPV;                 // channels per K-chunk: 128 bytes of a row
+    constexpr bool BF = sizeof(TI) == 2;
+    const TI *__restrict__ gin = reinterpret_cast<const TI *>(p.in);
+    const TI *__restrict__ gw = reinterpret_cast<const TI *>(p.w);
+    TO *__restrict__ gout = reinterpret_cast<TO *>(p.out);
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int AJ = BM / 32;  // float4 rows per thread for A
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
     const int py = cls >> 1, px = cls & 1;
 
     // ---- per-thread gather rows: row r_j = tid/8 + 32 j ----
-    const int c4 = (tid & 7) * 4;
+    const int c4 = (tid & 7) * EPV;   // this thread's 16-byte piece inside a chunk, in elements
     const int rsub = tid >> 3;
     int rbase[AJ];  // element offset of (b, iy0, ix0, 0); may be "negative pixel", guarded by iy/ix tests
     int riy0[AJ], rix0[AJ];
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
         rowoff[tid] = off;
     }
 
-    const int nchunks = (p.CI + 31) >> 5;
+    const int nchunks = (p.CI + KC - 1) / KC;
     const int ntaps = (MODE == 0) ? p.KH * p.KW : 4;
     const int nit = ntaps * nchunks;
 
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
             const int iy = riy0[j] + dy, ix = rix0[j] + dx;
             const int ok = cok & (iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW);
             const int off = ok ? rbase[j] + tapoff : 0;
-            ra[j] = *reinterpret_cast<const v4f *>(p.in + off);
+            ra[j] = *reinterpret_cast<const v4f *>(gin + off);
             m |= (unsigned)ok << j;
         }
 #pragma unroll
@@ -132,12 +142,12 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
             const int n = n0 + rsub + 32 * j;
             const int ok = cok & (n < p.CO);
             const int off = ok ? ((ws * p.CO + n) * p.CI + c0 + c4) : 0;
-            rb[j] = *reinterpret_cast<const v4f *>(p.w + off);
+            rb[j] = *reinterpret_cast<const v4f *>(gw + off);
             m |= (unsigned)ok << (16 + j);
         }
         okmask = m;
         // advance to the following chunk
-        g_c0 += 32;
+        g_c0 += KC;
         const int wrap = g_c0 >= p.CI;
         g_c0 = wrap ? 0 : g_c0;
         g_kw += wrap;
@@ -153,12 +163,21 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             v4f v = (okmask >> j) & 1u ? ra[j] : zero;
-            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + c4) = v;
+            if (RELU) {
+                if constexpr (BF) {   // a bf16 is negative exactly when its bit pattern is a negative int16
+                    s16x8 sv = __builtin_bit_cast(s16x8, v);
+                    const s16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    sv = __builtin_elementwise_max(sv, z8);
+                    v = __builtin_bit_cast(v4f, sv);
+                } else {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = v;
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j)
-            *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + c4) = (okmask >> (16 + j)) & 1u ? rb[j] : zero;
+            *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = (okmask >> (16 + j)) & 1u ? rb[j] : zero;
     };
 
     v16f acc[TM][TN];
@@ -179,13 +198,23 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v4f *>(a_base + i * 32 * LDS_PITCH + kk * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const v4f *>(b_base + j * 32 * LDS_PITCH + kk * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
+            if constexpr (BF) {
+                // lane (r, h) holds k = 16*kk + 8h + 0..7 of its row: exactly the 32x32x16 operand layout
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                           acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -226,30 +255,33 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
     }
     __syncthreads();
     const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
-    const bool vec_store = ((p.CO & 3) == 0) && nsg_aligned16_dev(p.out);
-    constexpr int N4 = BN / 4;
-    for (int f = tid; f < BM * N4; f += 256) {
-        const int row = f / N4;
-        const int cq = (f - row * N4) * 4;
+    constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
+    const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);
+    constexpr int NV = BN / EPO;
+    for (int f = tid; f < BM * NV; f += 256) {
+        const int row = f / NV;
+        const int cq = (f - row * NV) * EPO;
         const int off = rowoff[row];
         const int col = n0 + cq;
         if (off < 0 || col >= p.CO) continue;
-        v4f v = *reinterpret_cast<const v4f *>(Cs + row * CP + cq);
-        if (p.bias) {
-            v.x += p.bias[col];
-            if (col + 1 < p.CO) v.y += p.bias[col + 1];
-            if (col + 2 < p.CO) v.z += p.bias[col + 2];
-            if (col + 3 < p.CO) v.w += p.bias[col + 3];
+        float v[EPO];
+#pragma unroll
+        for (int e = 0; e < EPO; e += 4) {
+            const v4f t = *reinterpret_cast<const v4f *>(Cs + row * CP + cq + e);
+            v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
         }
-        if (tanh_out) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-        float *dst = p.out + (size_t)off + col;
-        if (vec_store && col + 3 < p.CO) {
-            *reinterpret_cast<v4f *>(dst) = v;
+#pragma unroll
+        for (int e = 0; e < EPO; ++e) {
+            if (p.bias && col + e < p.CO) v[e] += p.bias[col + e];
+            if (tanh_out) v[e] = tanhf(v[e]);
+        }
+        TO *dst = gout + (size_t)off + col;
+        if (vec_store && col + EPO - 1 < p.CO) {
+            Elem<TO>::store16(dst, v);
         } else {
-            dst[0] = v.x;
-            if (col + 1 < p.CO) dst[1] = v.y;
-            if (col + 2 < p.CO) dst[2] = v.z;
-            if (col + 3 < p.CO) dst[3] = v.w;
+#pragma unroll
+            for (int e = 0; e < EPO; ++e)
+                if (col + e < p.CO) Elem<TO>::put(dst + e, v[e]);
         }
     }
 
@@ -309,7 +341,7 @@ __global__ __launch_bounds__(256) void gather_gemm_f32(const GatherGemmParams p)
     }
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool RELU>
+template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
 int launch_one(const GatherGemmParams &p, hipStream_t s)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -323,21 +355,29 @@ int launch_one(const GatherGemmParams &p, hipStream_t s)
     dim3 grid((unsigned)gx, MODE == 0 ? 1 : 4, 1);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_gemm_f32<WM, WN, TM, TN, MODE, RELU>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nsg_fail((int)e, "gather_gemm: cannot reserve %zu bytes of LDS", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gather_gemm_f32<WM, WN, TM, TN, MODE, RELU>), grid, dim3(256), lds, s, p);
-    return nsg_check_launch("gather_gemm_f32");
+    hipLaunchKernelGGL((gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU>), grid, dim3(256), lds, s, p);
+    return nsg_check_launch("gather_gemm");
 }
 
-template <int WM, int WN, int TM, int TN>
+template <typename TI, typename TO, int WM, int WN, int TM, int TN>
 int launch_cfg(const GatherGemmParams &p, hipStream_t s)
 {
     const bool relu = (p.flags & NSG_RELU_IN) != 0;
-    if (p.mode == 0) return relu ? launch_one<WM, WN, TM, TN, 0, true>(p, s) : launch_one<WM, WN, TM, TN, 0, false>(p, s);
-    return relu ? launch_one<WM, WN, TM, TN, 1, true>(p, s) : launch_one<WM, WN, TM, TN, 1, false>(p, s);
+    if (p.mode == 0) return relu ? launch_one<TI, TO, WM, WN, TM, TN, 0, true>(p, s) : launch_one<TI, TO, WM, WN, TM, TN, 0, false>(p, s);
+    return relu ? launch_one<TI, TO, WM, WN, TM, TN, 1, true>(p, s) : launch_one<TI, TO, WM, WN, TM, TN, 1, false>(p, s);
+}
+
+template <typename TI, typename TO>
+int launch_typed(const GatherGemmParams &p, hipStream_t s)
+{
+    if (p.CO > 64) return launch_cfg<TI, TO, 2, 2, 2, 2>(p, s);   // 128 x 128
+    if (p.CO > 32) return launch_cfg<TI, TO, 2, 2, 2, 1>(p, s);   // 128 x 64
+    return launch_cfg<TI, TO, 4, 1, 1, 1>(p, s);                  // 128 x 32
 }
 
 }  // namespace
@@ -350,9 +390,11 @@ int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s)
 {
     if (p.M <= 0) return NSG_OK;
-    if (p.CI % 4 != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of 4", p.CI);
+    const int epv = p.in_dtype == NSG_BF16 ? 8 : 4;
+    if (p.CI % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of %d", p.CI, epv);
     if (!nsg_aligned16(p.in) || !nsg_aligned16(p.w)) return nsg_fail(NSG_E_INVALID, "gather_gemm: operands must be 16-byte aligned");
-    if (p.CO > 64) return launch_cfg<2, 2, 2, 2>(p, s);   // 128 x 128
-    if (p.CO > 32) return launch_cfg<2, 2, 2, 1>(p, s);   // 128 x 64
-    return launch_cfg<4, 1, 1, 1>(p, s);                  // 128 x 32
+    if (p.in_dtype == NSG_F32 && p.out_dtype == NSG_F32) return launch_typed<float, float>(p, s);
+    if (p.in_dtype == NSG_BF16 && p.out_dtype == NSG_BF16) return launch_typed<bf16_t, bf16_t>(p, s);
+    if (p.in_dtype == NSG_BF16 && p.out_dtype == NSG_F32) return launch_typed<bf16_t, float>(p, s);
+    return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: fp32 operands with bf16 output are not supported");
 }

@@ -27,14 +27,17 @@ namespace {
 
 constexpr int KP = 32;  // pixels per chunk
 
-template <int WM, int WN, int TM, int TN, bool ONEHOT, bool DIAG = false>
+template <typename TI, int WM, int WN, int TM, int TN, bool ONEHOT, bool DIAG = false>
 __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
 {
     constexpr int TA = WM * TM * 32;
     constexpr int TC = WN * TN * 32;
-    constexpr int PJ = TA / 32;  // float4 per thread per chunk for P (KP*TA/4/256)
-    constexpr int QJ = TC / 32;
-    constexpr int PA4 = TA / 4, QC4 = TC / 4;
+    constexpr int EPV = 16 / (int)sizeof(TI);            // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
+    constexpr int PA4 = TA / EPV, QC4 = TC / EPV;        // pieces per pixel row
+    constexpr int PJ = (KP * PA4 + 255) / 256;           // pieces per thread per chunk
+    constexpr int QJ = (KP * QC4 + 255) / 256;
+    const TI *__restrict__ gP = reinterpret_cast<const TI *>(p.P);
+    const TI *__restrict__ gQ = reinterpret_cast<const TI *>(p.Q);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ps = smem;                 // [2][KP][TA]
@@ -76,14 +79,14 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
         for (int j = 0; j < PJ; ++j) {
             const int f = tid + 256 * j;
             const int pix = f / PA4;
-            const int a4 = (f - pix * PA4) * 4;
+            const int a4 = (f - pix * PA4) * EPV;
             const int m = mb + pix;
-            const int ok = (m < mend) & ((a0 + a4) < p.A);
+            const int ok = (pix < KP) & (m < mend) & ((a0 + a4) < p.A);
             if (ONEHOT) {
                 ridx[S][j] = (int)p.idx[ok ? m : mbeg];
             } else {
                 const size_t off = ok ? ((size_t)m * p.A + a0 + a4) : 0;
-                rp[S][j] = *reinterpret_cast<const v4f *>(p.P + off);
+                rp[S][j] = *reinterpret_cast<const v4f *>(gP + off);
             }
             mk |= (unsigned)ok << j;
         }
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
         for (int j = 0; j < QJ; ++j) {
             const int f = tid + 256 * j;
             const int pix = f / QC4;
-            const int cc4 = (f - pix * QC4) * 4;
+            const int cc4 = (f - pix * QC4) * EPV;
             const int m = mb + pix;
             const int mm = m < mend ? m : mbeg;
             const int b = nsg_div(mm, p.div_phw);
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             const int px = rem - py * p.PW;
             const int qy = py * p.stride - p.pad + kh;
             const int qx = px * p.stride - p.pad + kw;
-            const int ok = (m < mend) & ((c0 + cc4) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
+            const int ok = (pix < KP) & (m < mend) & ((c0 + cc4) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
             const size_t off = ok ? (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + cc4) : 0;
-            rq[S][j] = *reinterpret_cast<const v4f *>(p.Q + off);
+            rq[S][j] = *reinterpret_cast<const v4f *>(gQ + off);
             mk |= (unsigned)ok << (16 + j);
         }
         okmask[S] = mk;
@@ -112,29 +115,53 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
         constexpr int S = decltype(set_c)::value;
         float *ps = Ps + buf * KP * TA;
         float *qs = Qs + buf * KP * TC;
-        const v4f zero = {0.f, 0.f, 0.f, 0.f};
+        // widen a staged 16-byte piece to EPV floats (fp32: as is; bf16: a 16-bit shift per element)
+        auto widen = [&](const v4f &raw, float *o) {
+            if constexpr (EPV == 4) {
+                o[0] = raw.x; o[1] = raw.y; o[2] = raw.z; o[3] = raw.w;
+            } else {
+                const float r0 = raw.x, r1 = raw.y, r2 = raw.z, r3 = raw.w;
+                const unsigned u[4] = {nsg_fbits(r0), nsg_fbits(r1), nsg_fbits(r2), nsg_fbits(r3)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { o[2 * i] = nsg_bitsf(u[i] << 16); o[2 * i + 1] = nsg_bitsf(u[i] & 0xffff0000u); }
+            }
+        };
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            v4f v;
+            const int f = tid + 256 * j;
+            if (f >= KP * PA4) continue;
+            float o[EPV];
+            const bool ok = (okmask[S] >> j) & 1u;
             if (ONEHOT) {
-                const int f = tid + 256 * j;
-                const int a4 = (f - (f / PA4) * PA4) * 4;
+                const int a4 = (f - (f / PA4) * PA4) * EPV;
                 const int code = ridx[S][j] - (a0 + a4);
-                v.x = code == 0 ? 1.f : 0.f;
-                v.y = code == 1 ? 1.f : 0.f;
-                v.z = code == 2 ? 1.f : 0.f;
-                v.w = code == 3 ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = (ok && code == e) ? 1.f : 0.f;
             } else {
-                v = rp[S][j];
-                v.x = fmaxf(v.x, lbp); v.y = fmaxf(v.y, lbp); v.z = fmaxf(v.z, lbp); v.w = fmaxf(v.w, lbp);
+                widen(rp[S][j], o);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = ok ? fmaxf(o[e], lbp) : 0.f;
             }
-            *reinterpret_cast<v4f *>(ps + (tid + 256 * j) * 4) = (okmask[S] >> j) & 1u ? v : zero;
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+                v4f v = {o[e], o[e + 1], o[e + 2], o[e + 3]};
+                *reinterpret_cast<v4f *>(ps + f * EPV + e) = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < QJ; ++j) {
-            v4f v = rq[S][j];
-            v.x = fmaxf(v.x, lbq); v.y = fmaxf(v.y, lbq); v.z = fmaxf(v.z, lbq); v.w = fmaxf(v.w, lbq);
-            *reinterpret_cast<v4f *>(qs + (tid + 256 * j) * 4) = (okmask[S] >> (16 + j)) & 1u ? v : zero;
+            const int f = tid + 256 * j;
+            if (f >= KP * QC4) continue;
+            float o[EPV];
+            const bool ok = (okmask[S] >> (16 + j)) & 1u;
+            widen(rq[S][j], o);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o[e] = ok ? fmaxf(o[e], lbq) : 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+                v4f v = {o[e], o[e + 1], o[e + 2], o[e + 3]};
+                *reinterpret_cast<v4f *>(qs + f * EPV + e) = v;
+            }
         }
     };
 
@@ -309,7 +336,7 @@ SlabPlan plan_slabs(int64_t Mp, int ntaps, int A, int C)
     return sp;
 }
 
-template <int WM, int WN, int TM, int TN, bool ONEHOT>
+template <typename TI, int WM, int WN, int TM, int TN, bool ONEHOT>
 int launch_wg1(const WgradParams &p, int nslab, hipStream_t s)
 {
     constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
@@ -319,12 +346,12 @@ int launch_wg1(const WgradParams &p, int nslab, hipStream_t s)
     dim3 grid(nslab, ntaps, tiles);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_f32<WM, WN, TM, TN, ONEHOT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_f32<TI, WM, WN, TM, TN, ONEHOT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_gemm_f32<WM, WN, TM, TN, ONEHOT>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((wgrad_gemm_f32<TI, WM, WN, TM, TN, ONEHOT>), grid, dim3(256), lds, s, p);
     return nsg_check_launch("wgrad_gemm_f32");
 }
 
@@ -334,14 +361,16 @@ int launch_wg_diag(const WgradParams &p, int nslab, hipStream_t s)
     constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
     const size_t lds = (size_t)2 * KP * (TA + TC) * sizeof(float);
     dim3 grid(nslab, p.KH * p.KW, (unsigned)(nsg_cdiv(p.A, TA) * nsg_cdiv(p.C, TC)));
-    hipLaunchKernelGGL((wgrad_gemm_f32<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((wgrad_gemm_f32<float, WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
     return nsg_check_launch("wgrad_gemm_f32<diag>");
 }
 
 template <int WM, int WN, int TM, int TN>
 int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
 {
-    return p.onehot ? launch_wg1<WM, WN, TM, TN, true>(p, nslab, s) : launch_wg1<WM, WN, TM, TN, false>(p, nslab, s);
+    if (p.onehot) return launch_wg1<float, WM, WN, TM, TN, true>(p, nslab, s);   // one-hot: Q (the scattered rows) is fp32
+    if (p.dtype == NSG_BF16) return launch_wg1<bf16_t, WM, WN, TM, TN, false>(p, nslab, s);
+    return launch_wg1<float, WM, WN, TM, TN, false>(p, nslab, s);
 }
 
 }  // namespace
@@ -357,7 +386,8 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     const int ntaps = p.KH * p.KW;
     if (p.Mp <= 0) return nsg_fail(NSG_E_INVALID, "wgrad: empty reduction");
     // one-hot rows are generated, not loaded: any number of codes works there
-    if ((!p.onehot && p.A % 4 != 0) || p.C % 4 != 0) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: channels (%d,%d) must be multiples of 4", p.A, p.C);
+    const int epv = (!p.onehot && p.dtype == NSG_BF16) ? 8 : 4;
+    if ((!p.onehot && p.A % epv != 0) || p.C % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: channels (%d,%d) must be multiples of %d", p.A, p.C, epv);
     if ((!p.onehot && !nsg_aligned16(p.P)) || !nsg_aligned16(p.Q)) return nsg_fail(NSG_E_INVALID, "wgrad: operands must be 16-byte aligned");
     const SlabPlan sp = plan_slabs(p.Mp, ntaps, p.A, p.C);
     const size_t need = (size_t)sp.nslab * ntaps * p.A * p.C * sizeof(float);

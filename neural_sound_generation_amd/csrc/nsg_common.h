@@ -8,6 +8,50 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;   // storage type of a bfloat16 element (bit pattern)
+
+// Bits of a float passed BY VALUE.  (__builtin_bit_cast applied directly to an ext-vector element
+// expression such as `v.y` reads element 0 with this clang -- always go through these helpers.)
+__host__ __device__ __forceinline__ unsigned nsg_fbits(float f) { return __builtin_bit_cast(unsigned, f); }
+__host__ __device__ __forceinline__ float nsg_bitsf(unsigned u) { return __builtin_bit_cast(float, u); }
+
+// fp32 -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32); bf16 bits -> fp32 is a 16-bit shift
+__device__ __forceinline__ bf16_t nsg_f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float nsg_bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
+// Elem<T>: N = elements per 16-byte access; load16 / store16 move N elements as floats
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load16(const float *p, float *o) { const v4f v = *reinterpret_cast<const v4f *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void store16(float *p, const float *o) { v4f v = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<v4f *>(p) = v; }
+    static __device__ __forceinline__ float get(const float *p) { return *p; }
+    static __device__ __forceinline__ void put(float *p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load16(const bf16_t *p, float *o)
+    {
+        const v4f raw = *reinterpret_cast<const v4f *>(p);
+        const float r0 = raw.x, r1 = raw.y, r2 = raw.z, r3 = raw.w;
+        const unsigned u[4] = {nsg_fbits(r0), nsg_fbits(r1), nsg_fbits(r2), nsg_fbits(r3)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = nsg_bitsf(u[i] << 16); o[2 * i + 1] = nsg_bitsf(u[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store16(bf16_t *p, const float *o)
+    {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(o[2 * i]) | ((unsigned)nsg_f2bf(o[2 * i + 1]) << 16);
+        v4f raw = {nsg_bitsf(u[0]), nsg_bitsf(u[1]), nsg_bitsf(u[2]), nsg_bitsf(u[3])};
+        *reinterpret_cast<v4f *>(p) = raw;
+    }
+    static __device__ __forceinline__ float get(const bf16_t *p) { return nsg_bf2f(*p); }
+    static __device__ __forceinline__ void put(bf16_t *p, float v) { *p = nsg_f2bf(v); }
+};
 
 // thread-local error text (never thrown across the ABI)
 void nsg_set_error(const char *fmt, ...);
@@ -47,10 +91,11 @@ __device__ __forceinline__ int nsg_div(int n, FastDiv f)
 
 // ---- implicit-GEMM parameter blocks (gemm_gather.hip / gemm_wgrad.hip) -------------------------
 struct GatherGemmParams {
-    const float *in;    // [B][IH][IW][CI]
-    const float *w;     // [tap image][CO][CI]
-    const float *bias;  // [CO] or null
-    float *out;         // [B][OH][OW][CO]
+    const void *in;     // [B][IH][IW][CI]      elements of in_dtype
+    const void *w;      // [tap image][CO][CI]  elements of in_dtype
+    const float *bias;  // [CO] fp32 or null
+    void *out;          // [B][OH][OW][CO]      elements of out_dtype
+    int in_dtype, out_dtype;   // NSG_F32 / NSG_BF16
     int B, IH, IW, CI;
     int OH, OW, CO;
     int KH, KW, stride, pad;
@@ -65,8 +110,9 @@ struct GatherGemmParams {
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p);
 
 struct WgradParams {
-    const float *P;      // [B][PH][PW][A]  tensor on the conv-OUTPUT pixel grid (rows of the reduction)
-    const float *Q;      // [B][QH][QW][C]  tensor on the conv-INPUT pixel grid, gathered per tap
+    const void *P;       // [B][PH][PW][A]  tensor on the conv-OUTPUT pixel grid (rows of the reduction), elements of dtype
+    const void *Q;       // [B][QH][QW][C]  tensor on the conv-INPUT pixel grid, gathered per tap, elements of dtype
+    int dtype;           // NSG_F32 / NSG_BF16 (bf16 operands are widened to fp32 while staged: fp32 accumulate AND fp32 MFMA)
     const int64_t *idx;  // one-hot mode: P[pix][a] = (idx[pix] == a)
     float *partial;      // [nslab][ntaps][A][C]
     int B, PH, PW, A;

@@ -11,7 +11,7 @@ from ctypes import byref, c_float, c_int32, c_int64, c_size_t, c_void_p
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, NSG_RELU_IN, NSG_TANH_OUT  # noqa: F401
+from ._lib import ConvDesc, NSG_RELU_IN, NSG_TANH_OUT, NSG_OUT_F32, NSG_F32, NSG_BF16  # noqa: F401
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -25,10 +25,22 @@ def _p(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+def nsg_dtype(torch_dtype) -> int:
+    if torch_dtype == torch.float32:
+        return NSG_F32
+    if torch_dtype == torch.bfloat16:
+        return NSG_BF16
+    raise _lib.NsgError(f"unsupported activation dtype {torch_dtype} (float32 or bfloat16)")
+
+
+def torch_dtype(nsg: int):
+    return torch.bfloat16 if nsg == NSG_BF16 else torch.float32
+
+
 def _chk(t, name, dtype=torch.float32):
     if not t.is_cuda:
         raise _lib.NsgError(f"{name}: expected a GPU tensor (this path has no CPU fallback)")
-    if t.dtype != dtype:
+    if dtype is not None and t.dtype != dtype:
         raise _lib.NsgError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise _lib.NsgError(f"{name}: expected a contiguous tensor")
@@ -159,19 +171,29 @@ def debug_dot(x, e, mode):
 # ------------------------------------------------------------------------------------------------
 # convolutions
 # ------------------------------------------------------------------------------------------------
-def conv_desc(B, IH, IW, C_in, C_out, k, stride, pad, transposed=False) -> ConvDesc:
+def conv_desc(B, IH, IW, C_in, C_out, k, stride, pad, transposed=False, dtype=torch.float32) -> ConvDesc:
+    """dtype: storage type of the layer's multi-channel activations and packed weights."""
     if transposed:
         OH, OW = (IH - 1) * stride - 2 * pad + k, (IW - 1) * stride - 2 * pad + k
     else:
         OH, OW = (IH + 2 * pad - k) // stride + 1, (IW + 2 * pad - k) // stride + 1
-    return ConvDesc(B, IH, IW, C_in, OH, OW, C_out, k, stride, pad, 1 if transposed else 0)
+    return ConvDesc(B, IH, IW, C_in, OH, OW, C_out, k, stride, pad, 1 if transposed else 0, nsg_dtype(dtype))
+
+
+def _in_dtype(d: ConvDesc):
+    """torch dtype of the layer INPUT tensor (single-channel images are always fp32)."""
+    return torch.float32 if d.C_in == 1 else torch_dtype(d.dtype)
+
+
+def _out_dtype(d: ConvDesc, flags=0):
+    return torch.float32 if (d.C_out == 1 or (flags & NSG_OUT_F32)) else torch_dtype(d.dtype)
 
 
 def pack_weights(d: ConvDesc, w, want_fwd=True, want_dgrad=True):
     _chk(w, "weight")
     n = _lib.query("nsg_packed_weight_floats", byref(d))
-    wf = torch.empty(n, dtype=torch.float32, device=w.device) if want_fwd else None
-    wd = torch.empty(n, dtype=torch.float32, device=w.device) if want_dgrad else None
+    wf = torch.empty(n, dtype=torch_dtype(d.dtype), device=w.device) if want_fwd else None
+    wd = torch.empty(n, dtype=torch_dtype(d.dtype), device=w.device) if want_dgrad else None
     _lib.call("nsg_pack_conv_weights", byref(d), _p(w), _p(wf), _p(wd), _stream())
     return wf, wd
 
@@ -183,10 +205,10 @@ def _conv_ws(d, device):
 
 def conv_forward(d: ConvDesc, x, w_fwd, bias, flags=0, out=None):
     """x NHWC (B,IH,IW,C_in) -> y NHWC (B,OH,OW,C_out)."""
-    _chk(x, "x")
+    _chk(x, "x", _in_dtype(d))
     if tuple(x.shape) != (d.B, d.IH, d.IW, d.C_in):
         raise _lib.NsgError(f"conv_forward: input shape {tuple(x.shape)} does not match descriptor {d.key()}")
-    y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=_out_dtype(d, flags), device=x.device)
     ws, nb = _conv_ws(d, x.device)
     timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
     t0 = KERNEL_TIMER.begin() if timed else None
@@ -199,10 +221,10 @@ def conv_forward(d: ConvDesc, x, w_fwd, bias, flags=0, out=None):
 def conv_forward_bnstats(d: ConvDesc, x, w_fwd, bias, flags=0, running_mean=None, running_var=None, eps=BN_EPS,
                          momentum=BN_MOMENTUM, out=None):
     """conv forward + training-mode BatchNorm statistics of the output in one pass -> (y, mean, invstd)."""
-    _chk(x, "x")
+    _chk(x, "x", _in_dtype(d))
     if tuple(x.shape) != (d.B, d.IH, d.IW, d.C_in):
         raise _lib.NsgError(f"conv_forward_bnstats: input shape {tuple(x.shape)} does not match descriptor {d.key()}")
-    y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty(d.B, d.OH, d.OW, d.C_out, dtype=_out_dtype(d, flags), device=x.device)
     mean = torch.empty(d.C_out, dtype=torch.float32, device=x.device)
     invstd = torch.empty(d.C_out, dtype=torch.float32, device=x.device)
     ws, nb = _conv_ws(d, x.device)
@@ -216,10 +238,10 @@ def conv_forward_bnstats(d: ConvDesc, x, w_fwd, bias, flags=0, running_mean=None
 
 
 def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
-    _chk(dy, "dy")
+    _chk(dy, "dy", _out_dtype(d))
     if tuple(dy.shape) != (d.B, d.OH, d.OW, d.C_out):
         raise _lib.NsgError(f"conv_dgrad: dy shape {tuple(dy.shape)} does not match descriptor {d.key()}")
-    dx = out if out is not None else torch.empty(d.B, d.IH, d.IW, d.C_in, dtype=torch.float32, device=dy.device)
+    dx = out if out is not None else torch.empty(d.B, d.IH, d.IW, d.C_in, dtype=_in_dtype(d), device=dy.device)
     ws, nb = _conv_ws(d, dy.device)
     timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
     t0 = KERNEL_TIMER.begin() if timed else None
@@ -230,7 +252,7 @@ def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
 
 
 def conv_wgrad(d: ConvDesc, x, dy, w_shape, flags=0, dw=None, dbias=None, want_bias=True):
-    _chk(x, "x"); _chk(dy, "dy")
+    _chk(x, "x", _in_dtype(d)); _chk(dy, "dy", _out_dtype(d))
     if dw is None:
         dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     if dbias is None and want_bias:

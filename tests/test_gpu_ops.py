@@ -262,6 +262,69 @@ def test_conv_forward_with_fused_bn_statistics(case):
     np.testing.assert_allclose(invstd.cpu().numpy(), i2.cpu().numpy(), rtol=1e-5)
 
 
+BF16_CASES = [
+    (2, 10, 12, 16, 16, 3, 1, 1, False, True),     # ResBlock 3x3 + fused ReLU
+    (2, 10, 12, 16, 16, 1, 1, 0, False, False),    # 1x1
+    (2, 11, 15, 16, 24, 4, 2, 1, False, False),    # stride-2, odd extents
+    (2, 6, 7, 16, 16, 4, 2, 1, True, True),        # transposed + fused ReLU
+    (2, 20, 16, 1, 16, 4, 2, 1, False, False),     # single input channel (fp32 image in)
+    (2, 10, 8, 16, 1, 4, 2, 1, True, False),       # single output channel (fp32 image out)
+    (1, 20, 64, 128, 128, 3, 1, 1, False, True),   # full width
+    (1, 8, 16, 256, 256, 4, 2, 1, False, False),   # two column tiles
+    (1, 4, 8, 128, 128, 4, 2, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=str)
+def test_conv_bf16_mode(case):
+    """bf16 storage / bf16 MFMA with fp32 accumulation.  Reference: fp32 ATen on the SAME bf16-rounded
+    operands, so the only differences are accumulation order and the final rounding of the output to
+    bf16 (relative 2^-8); gradients w.r.t. weights stay fp32."""
+    B, IH, IW, Ci, Co, k, s, p, tr, relu_in = case
+    g = torch.Generator().manual_seed(sum(case[:9]))
+    bf = torch.bfloat16
+
+    def rnd(t):   # round to bf16 values, keep fp32 storage
+        return t.to(bf).float()
+
+    x = rnd(torch.randn(B, Ci, IH, IW, generator=g)) if Ci > 1 else torch.randn(B, Ci, IH, IW, generator=g)
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = torch.randn(*wshape, generator=g) * 0.1
+    b = torch.randn(Co, generator=g) * 0.1
+    wq = rnd(w)                                     # what the packed bf16 image holds
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    xin = F.relu(xr) if relu_in else xr
+    if Ci == 1:
+        xin_eff = rnd(xin)                           # the im2col image of the fp32 input is stored in bf16
+    else:
+        xin_eff = xin
+    y = F.conv_transpose2d(xin_eff, wr, br, stride=s, padding=p) if tr else F.conv2d(xin_eff, wr, br, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    dyq = rnd(dy) if Co > 1 else dy
+    gx, gw, gb = torch.autograd.grad(y, [xin_eff if Ci > 1 else xr, wr, br], dyq)
+
+    d = ops.conv_desc(B, IH, IW, Ci, Co, k, s, p, transposed=tr, dtype=bf)
+    wf, wd = ops.pack_weights(d, gpu(w))
+    assert wf.dtype == bf
+    xg = gpu(nhwc(x)).to(bf) if Ci > 1 else gpu(nhwc(x))
+    yg = ops.conv_forward(d, xg, wf, gpu(b), flags=ops.NSG_RELU_IN if relu_in else 0)
+    assert yg.dtype == (bf if Co > 1 else torch.float32)
+    _close(nchw(yg.float().cpu()), y.detach(), tol=1e-2 if Co > 1 else 2e-3, what="forward")
+    if Co > 1:
+        yf = ops.conv_forward(d, xg, wf, gpu(b), flags=(ops.NSG_RELU_IN if relu_in else 0) | ops.NSG_OUT_F32)
+        assert yf.dtype == torch.float32
+        _close(nchw(yf.cpu()), y.detach(), tol=2e-3, what="forward (fp32 out)")
+    dyg = gpu(nhwc(dyq)).to(bf) if Co > 1 else gpu(nhwc(dyq))
+    dxg = ops.conv_dgrad(d, dyg, wd)
+    _close(nchw(dxg.float().cpu()), gx, tol=1e-2, what="dgrad")
+    dwg, dbg = ops.conv_wgrad(d, xg, dyg, wshape, flags=ops.NSG_RELU_IN if relu_in else 0)
+    assert dwg.dtype == torch.float32
+    _close(dwg.cpu(), gw, tol=2e-3, what="wgrad")
+    _close(dbg.cpu(), gb, tol=1e-4, what="bias grad")
+
+
 def test_conv_rejects_unsupported_geometry():
     from neural_sound_generation_amd._lib import NsgError
     d = ops.conv_desc(1, 8, 8, 6, 8, 3, 1, 1)  # C_in not a multiple of 4
