@@ -173,36 +173,44 @@ NSG_API size_t nsg_bn_workspace_bytes(int64_t M, int32_t C);
 /* Training-mode statistics: mean[C], invstd[C] = 1/sqrt(biased var + eps); if running_mean/var are
  * non-NULL they are updated with `momentum` (running_var takes the unbiased variance), as
  * F.batch_norm(training=True) does. */
-NSG_API int nsg_bn_stats(const float *x, int64_t M, int32_t C, float eps, float momentum, float *mean, float *invstd,
-                         float *running_mean, float *running_var, void *workspace, size_t workspace_bytes,
-                         void *stream);
+NSG_API int nsg_bn_stats(const void *x, int64_t M, int32_t C, int32_t dtype, float eps, float momentum, float *mean,
+                         float *invstd, float *running_mean, float *running_var, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* Eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps). */
 NSG_API int nsg_bn_eval_stats(const float *running_mean, const float *running_var, int32_t C, float eps, float *mean,
                               float *invstd, void *stream);
 
+/* (BatchNorm entry points: x / residual / y_relu / dy / dx hold elements of `dtype` (NSG_F32 or NSG_BF16,
+ * void* below; nsg_bn_apply may write y in a different y_dtype); statistics, per-channel parameters and all
+ * arithmetic are fp32.  bf16 needs C % 8 == 0.) */
 /* y = (x-mean)*invstd*gamma + beta; relu != 0: y = max(0,y); residual != NULL: y += residual
  * (relu_residual != 0: y += max(0,residual) -- the ResBlock's in-place-ReLU'd skip, models.py:149,158). */
-NSG_API int nsg_bn_apply(const float *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
-                         const float *residual, float *y, int64_t M, int32_t C, int32_t relu, int32_t relu_residual,
-                         void *stream);
+NSG_API int nsg_bn_apply(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                         const void *residual, void *y, int64_t M, int32_t C, int32_t relu, int32_t relu_residual,
+                         int32_t dtype, int32_t y_dtype, void *stream);
 
 /* Backward of the call above with respect to x, gamma, beta.  y_relu: the forward OUTPUT when
  * relu != 0 was used (its sign is the ReLU mask), else NULL.  dgamma/dbeta [C] overwritten.
  * dx_colsum [C] or NULL: column sums of dx, i.e. the bias gradient of the convolution that feeds
  * this BatchNorm (autograd of nn.Conv2d's bias at src/models.py:150,153,165,179), produced by the
  * kernel that writes dx instead of a second pass over it. */
-NSG_API int nsg_bn_backward(const float *x, const float *y_relu, const float *dy, const float *mean,
-                            const float *invstd, const float *gamma, float *dx, float *dgamma, float *dbeta,
-                            float *dx_colsum, int64_t M, int32_t C, void *workspace, size_t workspace_bytes,
-                            void *stream);
+NSG_API int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const float *mean,
+                            const float *invstd, const float *gamma, void *dx, float *dgamma, float *dbeta,
+                            float *dx_colsum, int64_t M, int32_t C, int32_t dtype, void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Element-wise, losses, optimiser                         src/train.py:118-136
  * ------------------------------------------------------------------------------------------- */
 
-/* dx = (a + b) * (x > 0)   (b may be NULL): gradient through the ResBlock's leading in-place ReLU. */
-NSG_API int nsg_relu_backward_add(const float *a, const float *b, const float *x, float *dx, int64_t n, void *stream);
+/* dx = (a + b) * (x > 0)   (b may be NULL): gradient through the ResBlock's leading in-place ReLU.
+ * All four tensors hold elements of `dtype`. */
+NSG_API int nsg_relu_backward_add(const void *a, const void *b, const void *x, void *dx, int64_t n, int32_t dtype,
+                                  void *stream);
+
+/* dst = src with a change of storage type (fp32 <-> bf16, round to nearest even). */
+NSG_API int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int64_t n, void *stream);
 
 /* dx = g * (1 - y*y): backward of nn.Tanh (models.py:183) from its output y. */
 NSG_API int nsg_tanh_backward(const float *g, const float *y, float *dx, int64_t n, void *stream);
@@ -213,11 +221,11 @@ NSG_API int nsg_add(const float *a, const float *b, float *y, int64_t n, void *s
 /* Speaker-conditioned decoder (extension; BASELINE configs[2]; not in the reference, whose VQVAE
  * ignores the speaker id g, src/train.py:114):  y[b][r][:] = x[b][r][:] + rows[b][:] for the
  * rows_per_clip pixels r of clip b, and its gradient w.r.t. rows: out[b][:] = sum_r x[b][r][:]. */
-NSG_API int nsg_add_per_clip(const float *x, const float *rows, float *y, int32_t B, int64_t rows_per_clip, int32_t C,
-                             void *stream);
+NSG_API int nsg_add_per_clip(const float *x, const float *rows, void *y, int32_t B, int64_t rows_per_clip, int32_t C,
+                             int32_t y_dtype, void *stream);
 NSG_API size_t nsg_clip_colsum_workspace_bytes(int32_t B, int32_t C);
-NSG_API int nsg_clip_colsum(const float *x, int32_t B, int64_t rows_per_clip, int32_t C, float *out, void *workspace,
-                            size_t workspace_bytes, void *stream);
+NSG_API int nsg_clip_colsum(const void *x, int32_t dtype, int32_t B, int64_t rows_per_clip, int32_t C, float *out,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 NSG_API size_t nsg_reduce_workspace_bytes(int64_t n);
 
@@ -229,10 +237,11 @@ NSG_API int nsg_mse_padded(const float *a, const float *c, int64_t rows, int32_t
 
 /* loss_out[0] = mean((q - z)^2) over n elements (train.py:131,133: both terms have this value);
  * dz (or NULL) = dz_scale * 2/n * (z - q) (+ dz_add if non-NULL: the straight-through gradient),
- * dq (or NULL) = dq_scale * 2/n * (q - z). */
+ * dq (or NULL) = dq_scale * 2/n * (q - z).  z, q, dq are fp32 (the quantiser works in fp32 in both
+ * modes); dz and dz_add hold elements of grad_dtype (the encoder-side activation gradient). */
 NSG_API int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_scale, float dq_scale,
-                          const float *dz_add, float *loss_out, float *dz, float *dq, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          const void *dz_add, float *loss_out, void *dz, float *dq, int32_t grad_dtype,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* torch.optim.Adam step (src/main.py:124 defaults, no weight decay, no amsgrad) over one flat
  * fp32 buffer.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce).

@@ -51,19 +51,20 @@ _SIGS = {
     "nsg_conv_dgrad": (None, [_D, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_conv_wgrad": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "nsg_bn_stats": (None, [_P, c_int64, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "nsg_bn_stats": (None, [_P, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_bn_eval_stats": (None, [_P, _P, c_int32, c_float, _P, _P, _P]),
-    "nsg_bn_apply": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
-    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, c_size_t, _P]),
-    "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, _P]),
+    "nsg_bn_apply": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, c_int32, _P]),
+    "nsg_convert": (None, [_P, c_int32, _P, c_int32, c_int64, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),
     "nsg_add": (None, [_P, _P, _P, c_int64, _P]),
-    "nsg_add_per_clip": (None, [_P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    "nsg_add_per_clip": (None, [_P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
     "nsg_clip_colsum_workspace_bytes": (c_size_t, [c_int32, c_int32]),
-    "nsg_clip_colsum": (None, [_P, c_int32, c_int64, c_int32, _P, _P, c_size_t, _P]),
+    "nsg_clip_colsum": (None, [_P, c_int32, c_int32, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "nsg_reduce_workspace_bytes": (c_size_t, [c_int64]),
     "nsg_mse_padded": (None, [_P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, c_size_t, _P]),
-    "nsg_vq_losses": (None, [_P, _P, c_int64, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "nsg_vq_losses": (None, [_P, _P, c_int64, c_float, c_float, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_adam_step": (None, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, _P]),
     "nsg_debug_dot": (None, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
 }

@@ -20,21 +20,51 @@ struct Vec<4> { typedef v4f T; };
 template <>
 struct Vec<1> { typedef float T; };
 
-template <int V>
-__global__ __launch_bounds__(256) void relu_bwd_add_kernel(const float *a, const float *b, const float *x, float *dx, int64_t nv)
+// dx = (a + b) * (x > 0), elements of type T (16-byte accesses) -- nv counts 16-byte pieces
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_add_typed_kernel(const T *a, const T *b, const T *x, T *dx, int64_t nv)
 {
-    typedef typename Vec<V>::T T;
+    constexpr int W = Elem<T>::N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-        T g = reinterpret_cast<const T *>(a)[i];
-        if (b) g += reinterpret_cast<const T *>(b)[i];
-        const T xv = reinterpret_cast<const T *>(x)[i];
-        if constexpr (V == 4) {
-            g.x = xv.x > 0.f ? g.x : 0.f; g.y = xv.y > 0.f ? g.y : 0.f;
-            g.z = xv.z > 0.f ? g.z : 0.f; g.w = xv.w > 0.f ? g.w : 0.f;
-        } else {
-            g = xv > 0.f ? g : 0.f;
+        float g[W], xv[W];
+        ldw<T, W>(a + i * W, g);
+        ldw<T, W>(x + i * W, xv);
+        if (b) {
+            float bv[W];
+            ldw<T, W>(b + i * W, bv);
+#pragma unroll
+            for (int e = 0; e < W; ++e) g[e] += bv[e];
         }
-        reinterpret_cast<T *>(dx)[i] = g;
+#pragma unroll
+        for (int e = 0; e < W; ++e) g[e] = xv[e] > 0.f ? g[e] : 0.f;
+        stw<T, W>(dx + i * W, g);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_add_scalar_kernel(const T *a, const T *b, const T *x, T *dx, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = Elem<T>::get(a + i);
+        if (b) g += Elem<T>::get(b + i);
+        Elem<T>::put(dx + i, Elem<T>::get(x + i) > 0.f ? g : 0.f);
+    }
+}
+
+// dst = src with a change of storage type
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS *src, TD *dst, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<TD>::put(dst + i, Elem<TS>::get(src + i));
+}
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_vec_kernel(const TS *src, TD *dst, int64_t nv)
+{
+    constexpr int W = Width<TS, TD>::W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[W];
+        ldw<TS, W>(src + i * W, v);
+        stw<TD, W>(dst + i * W, v);
     }
 }
 
@@ -109,26 +139,40 @@ __global__ __launch_bounds__(256) void mse_padded_kernel(const float *__restrict
     block_sum_store(acc, partial);
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void vq_losses_kernel(const float *__restrict__ z, const float *__restrict__ q, int64_t nv,
-                                                        float zscale, float qscale, const float *__restrict__ dz_add,
-                                                        float *__restrict__ dz, float *__restrict__ dq, double *partial)
+// z, q fp32 (the VQ works in fp32 in both modes); dz / dz_add of type TG (the encoder-side gradient),
+// dq fp32 (it feeds the fp32 codebook scatter).  n counts elements; VEC: 8 elements per thread.
+template <typename TG, bool VEC>
+__global__ __launch_bounds__(256) void vq_losses_kernel(const float *__restrict__ z, const float *__restrict__ q, int64_t n,
+                                                        float zscale, float qscale, const TG *__restrict__ dz_add,
+                                                        TG *__restrict__ dz, float *__restrict__ dq, double *partial)
 {
-    typedef typename Vec<V>::T T;
+    constexpr int W = VEC ? 8 : 1;
+    const int64_t nv = n / W;
     double acc = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-        const T d = reinterpret_cast<const T *>(z)[i] - reinterpret_cast<const T *>(q)[i];
-        if constexpr (V == 4) {
-            acc += (double)(d.x * d.x) + (double)(d.y * d.y) + (double)(d.z * d.z) + (double)(d.w * d.w);
-        } else {
-            acc += (double)(d * d);
-        }
+        float zv[W], qv[W], d[W];
+        if constexpr (VEC) { ldw<float, 8>(z + i * 8, zv); ldw<float, 8>(q + i * 8, qv); }
+        else { zv[0] = z[i]; qv[0] = q[i]; }
+#pragma unroll
+        for (int e = 0; e < W; ++e) { d[e] = zv[e] - qv[e]; acc += (double)(d[e] * d[e]); }
         if (dz) {
-            T g = d * zscale;
-            if (dz_add) g += reinterpret_cast<const T *>(dz_add)[i];
-            reinterpret_cast<T *>(dz)[i] = g;
+            float g[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) g[e] = d[e] * zscale;
+            if (dz_add) {
+                float av[W];
+                if constexpr (VEC) ldw<TG, 8>(dz_add + i * 8, av); else av[0] = Elem<TG>::get(dz_add + i);
+#pragma unroll
+                for (int e = 0; e < W; ++e) g[e] += av[e];
+            }
+            if constexpr (VEC) stw<TG, 8>(dz + i * 8, g); else Elem<TG>::put(dz + i, g[0]);
         }
-        if (dq) reinterpret_cast<T *>(dq)[i] = d * (-qscale);
+        if (dq) {
+            float g[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) g[e] = d[e] * (-qscale);
+            if constexpr (VEC) stw<float, 8>(dq + i * 8, g); else dq[i] = g[0];
+        }
     }
     block_sum_store(acc, partial);
 }
@@ -157,41 +201,60 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
     }
 }
 
-// y[b][r][:] = x[b][r][:] + rows[b][:]   (speaker embedding broadcast over a clip's pixels)
-__global__ __launch_bounds__(256) void add_per_clip_kernel(const float *__restrict__ x, const float *__restrict__ rows, float *__restrict__ y,
-                                                           int64_t n4, int C4, int64_t per_clip4)
+// y[b][r][:] = x[b][r][:] + rows[b][:]   (speaker embedding broadcast over a clip's pixels); x, rows fp32, y of type TY
+template <typename TY>
+__global__ __launch_bounds__(256) void add_per_clip_kernel(const float *__restrict__ x, const float *__restrict__ rows, TY *__restrict__ y,
+                                                           int64_t nw, int CW, int64_t per_clip_w)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / per_clip4;
-        const int c = (int)(i % C4);
-        const v4f r = *reinterpret_cast<const v4f *>(rows + (b * C4 + c) * 4);
-        *reinterpret_cast<v4f *>(y + i * 4) = *reinterpret_cast<const v4f *>(x + i * 4) + r;
+    constexpr int W = Width<float, TY>::W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per_clip_w;
+        const int c = (int)(i % CW);
+        float xv[W], rv[W];
+        ldw<float, W>(x + i * W, xv);
+        ldw<float, W>(rows + (b * CW + c) * W, rv);
+#pragma unroll
+        for (int e = 0; e < W; ++e) xv[e] += rv[e];
+        stw<TY, W>(y + i * W, xv);
     }
 }
 
 // partial[b][s][:] = sum of rows [s*R, (s+1)*R) of clip b;  then out[b][:] = sum_s partial (fixed order)
-__global__ __launch_bounds__(256) void clip_colsum_partial_kernel(const float *__restrict__ x, int rows_per_clip, int C, int slabs,
+template <typename T>
+__global__ __launch_bounds__(256) void clip_colsum_partial_kernel(const T *__restrict__ x, int rows_per_clip, int C, int slabs,
                                                                   float *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) float red[256 * 4];
-    const int C4 = C >> 2;
-    const int rgroups = 256 / C4;
+    constexpr int W = Elem<T>::N;
+    __shared__ float red[256 * W];
+    const int CW = C / W;
+    const int rgroups = 256 / CW;
     const int tid = threadIdx.x;
-    const int cg = tid % C4, rg = tid / C4;
+    const int cg = tid % CW, rg = tid / CW;
     const int b = blockIdx.x / slabs, sl = blockIdx.x % slabs;
     const int R = (rows_per_clip + slabs - 1) / slabs;
     const int r0 = sl * R, r1 = min(rows_per_clip, r0 + R);
-    const float *base = x + (size_t)b * rows_per_clip * C;
-    v4f s = {0.f, 0.f, 0.f, 0.f};
+    const T *base = x + (size_t)b * rows_per_clip * C;
     if (rg < rgroups) {
-        for (int r = r0 + rg; r < r1; r += rgroups) s += *reinterpret_cast<const v4f *>(base + (size_t)r * C + cg * 4);
-        *reinterpret_cast<v4f *>(red + (rg * C4 + cg) * 4) = s;
+        float s[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) s[e] = 0.f;
+        for (int r = r0 + rg; r < r1; r += rgroups) {
+            float v[W];
+            ldw<T, W>(base + (size_t)r * C + cg * W, v);
+#pragma unroll
+            for (int e = 0; e < W; ++e) s[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < W; ++e) red[(rg * CW + cg) * W + e] = s[e];
     }
     __syncthreads();
-    if (tid < C4) {
-        v4f t = {0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < rgroups; ++g) t += *reinterpret_cast<const v4f *>(red + (g * C4 + tid) * 4);
-        *reinterpret_cast<v4f *>(partial + (size_t)blockIdx.x * C + tid * 4) = t;
+    if (tid < CW) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float t = 0.f;
+            for (int g = 0; g < rgroups; ++g) t += red[(g * CW + tid) * W + e];
+            partial[(size_t)blockIdx.x * C + tid * W + e] = t;
+        }
     }
 }
 __global__ void clip_colsum_final_kernel(const float *__restrict__ partial, int B, int slabs, int C, float *__restrict__ out)
@@ -211,16 +274,46 @@ constexpr int RED_BLOCKS = 1024;
 
 extern "C" {
 
-int nsg_relu_backward_add(const float *a, const float *b, const float *x, float *dx, int64_t n, void *stream)
+int nsg_relu_backward_add(const void *a, const void *b, const void *x, void *dx, int64_t n, int32_t dtype, void *stream)
 {
     NSG_REQUIRE(a && x && dx && n >= 0, NSG_E_INVALID, "nsg_relu_backward_add: bad argument");
+    NSG_REQUIRE(dtype == NSG_F32 || dtype == NSG_BF16, NSG_E_INVALID, "nsg_relu_backward_add: unknown dtype");
     if (n == 0) return NSG_OK;
     hipStream_t s = (hipStream_t)stream;
-    if ((n & 3) == 0 && nsg_aligned16(a) && nsg_aligned16(x) && nsg_aligned16(dx) && (!b || nsg_aligned16(b)))
-        hipLaunchKernelGGL((relu_bwd_add_kernel<4>), dim3(ew_blocks(n / 4)), dim3(256), 0, s, a, b, x, dx, n / 4);
-    else
-        hipLaunchKernelGGL((relu_bwd_add_kernel<1>), dim3(ew_blocks(n)), dim3(256), 0, s, a, b, x, dx, n);
+    const int W = dtype == NSG_BF16 ? 8 : 4;
+    const bool vec = (n % W) == 0 && nsg_aligned16(a) && nsg_aligned16(x) && nsg_aligned16(dx) && (!b || nsg_aligned16(b));
+    if (dtype == NSG_BF16) {
+        typedef bf16_t T;
+        if (vec) hipLaunchKernelGGL((relu_bwd_add_typed_kernel<T>), dim3(ew_blocks(n / W)), dim3(256), 0, s, (const T *)a, (const T *)b, (const T *)x, (T *)dx, n / W);
+        else     hipLaunchKernelGGL((relu_bwd_add_scalar_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, s, (const T *)a, (const T *)b, (const T *)x, (T *)dx, n);
+    } else {
+        typedef float T;
+        if (vec) hipLaunchKernelGGL((relu_bwd_add_typed_kernel<T>), dim3(ew_blocks(n / W)), dim3(256), 0, s, (const T *)a, (const T *)b, (const T *)x, (T *)dx, n / W);
+        else     hipLaunchKernelGGL((relu_bwd_add_scalar_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, s, (const T *)a, (const T *)b, (const T *)x, (T *)dx, n);
+    }
     return nsg_check_launch("relu_bwd_add_kernel");
+}
+
+int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int64_t n, void *stream)
+{
+    NSG_REQUIRE(src && dst && n >= 0, NSG_E_INVALID, "nsg_convert: bad argument");
+    NSG_REQUIRE((src_dtype == NSG_F32 || src_dtype == NSG_BF16) && (dst_dtype == NSG_F32 || dst_dtype == NSG_BF16), NSG_E_INVALID,
+                "nsg_convert: unknown dtype");
+    if (n == 0) return NSG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int W = (src_dtype == NSG_BF16 || dst_dtype == NSG_BF16) ? 8 : 4;
+    const bool vec = (n % W) == 0 && nsg_aligned16(src) && nsg_aligned16(dst);
+#define NSG_CVT(TS, TD)                                                                                                                   \
+    do {                                                                                                                                  \
+        if (vec) hipLaunchKernelGGL((convert_vec_kernel<TS, TD>), dim3(ew_blocks(n / W)), dim3(256), 0, s, (const TS *)src, (TD *)dst, n / W); \
+        else     hipLaunchKernelGGL((convert_kernel<TS, TD>), dim3(ew_blocks(n)), dim3(256), 0, s, (const TS *)src, (TD *)dst, n);          \
+    } while (0)
+    if (src_dtype == NSG_F32 && dst_dtype == NSG_BF16) NSG_CVT(float, bf16_t);
+    else if (src_dtype == NSG_BF16 && dst_dtype == NSG_F32) NSG_CVT(bf16_t, float);
+    else if (src_dtype == NSG_F32) NSG_CVT(float, float);
+    else NSG_CVT(bf16_t, bf16_t);
+#undef NSG_CVT
+    return nsg_check_launch("convert_kernel");
 }
 
 int nsg_tanh_backward(const float *g, const float *y, float *dx, int64_t n, void *stream)
@@ -247,29 +340,39 @@ int nsg_add(const float *a, const float *b, float *y, int64_t n, void *stream)
     return nsg_check_launch("add_kernel");
 }
 
-int nsg_add_per_clip(const float *x, const float *rows, float *y, int32_t B, int64_t rows_per_clip, int32_t C, void *stream)
+int nsg_add_per_clip(const float *x, const float *rows, void *y, int32_t B, int64_t rows_per_clip, int32_t C, int32_t y_dtype,
+                     void *stream)
 {
     NSG_REQUIRE(x && rows && y && B > 0 && rows_per_clip > 0 && C > 0, NSG_E_INVALID, "nsg_add_per_clip: bad argument");
-    NSG_REQUIRE(C % 4 == 0 && nsg_aligned16(x) && nsg_aligned16(rows) && nsg_aligned16(y), NSG_E_UNSUPPORTED,
-                "nsg_add_per_clip: C must be a multiple of 4 and pointers 16-byte aligned");
-    const int64_t n4 = (int64_t)B * rows_per_clip * C / 4;
-    hipLaunchKernelGGL(add_per_clip_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, x, rows, y, n4, C / 4,
-                       rows_per_clip * (C / 4));
+    NSG_REQUIRE(y_dtype == NSG_F32 || y_dtype == NSG_BF16, NSG_E_INVALID, "nsg_add_per_clip: unknown dtype");
+    const int W = y_dtype == NSG_BF16 ? 8 : 4;
+    NSG_REQUIRE(C % W == 0 && nsg_aligned16(x) && nsg_aligned16(rows) && nsg_aligned16(y), NSG_E_UNSUPPORTED,
+                "nsg_add_per_clip: C must be a multiple of %d and pointers 16-byte aligned", W);
+    const int64_t nw = (int64_t)B * rows_per_clip * C / W;
+    if (y_dtype == NSG_BF16)
+        hipLaunchKernelGGL((add_per_clip_kernel<bf16_t>), dim3(ew_blocks(nw)), dim3(256), 0, (hipStream_t)stream, x, rows, (bf16_t *)y, nw, C / W, rows_per_clip * (C / W));
+    else
+        hipLaunchKernelGGL((add_per_clip_kernel<float>), dim3(ew_blocks(nw)), dim3(256), 0, (hipStream_t)stream, x, rows, (float *)y, nw, C / W, rows_per_clip * (C / W));
     return nsg_check_launch("add_per_clip_kernel");
 }
 
 size_t nsg_clip_colsum_workspace_bytes(int32_t B, int32_t C) { return (size_t)(B > 0 ? B : 0) * CLIP_SLABS * (C > 0 ? C : 0) * sizeof(float); }
 
-int nsg_clip_colsum(const float *x, int32_t B, int64_t rows_per_clip, int32_t C, float *out, void *workspace,
+int nsg_clip_colsum(const void *x, int32_t dtype, int32_t B, int64_t rows_per_clip, int32_t C, float *out, void *workspace,
                     size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(x && out && B > 0 && rows_per_clip > 0 && C > 0, NSG_E_INVALID, "nsg_clip_colsum: bad argument");
-    NSG_REQUIRE(C % 4 == 0 && C <= 1024 && nsg_aligned16(x) && rows_per_clip < (1ll << 31), NSG_E_UNSUPPORTED,
-                "nsg_clip_colsum: C must be a multiple of 4 (<= 1024), x 16-byte aligned");
+    NSG_REQUIRE(dtype == NSG_F32 || dtype == NSG_BF16, NSG_E_INVALID, "nsg_clip_colsum: unknown dtype");
+    const int W = dtype == NSG_BF16 ? 8 : 4;
+    NSG_REQUIRE(C % W == 0 && C <= 1024 && nsg_aligned16(x) && rows_per_clip < (1ll << 31), NSG_E_UNSUPPORTED,
+                "nsg_clip_colsum: C must be a multiple of %d (<= 1024), x 16-byte aligned", W);
     NSG_REQUIRE(workspace && workspace_bytes >= nsg_clip_colsum_workspace_bytes(B, C), NSG_E_WORKSPACE, "nsg_clip_colsum: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float *partial = reinterpret_cast<float *>(workspace);
-    hipLaunchKernelGGL(clip_colsum_partial_kernel, dim3(B * CLIP_SLABS), dim3(256), 0, s, x, (int)rows_per_clip, C, CLIP_SLABS, partial);
+    if (dtype == NSG_BF16)
+        hipLaunchKernelGGL((clip_colsum_partial_kernel<bf16_t>), dim3(B * CLIP_SLABS), dim3(256), 0, s, (const bf16_t *)x, (int)rows_per_clip, C, CLIP_SLABS, partial);
+    else
+        hipLaunchKernelGGL((clip_colsum_partial_kernel<float>), dim3(B * CLIP_SLABS), dim3(256), 0, s, (const float *)x, (int)rows_per_clip, C, CLIP_SLABS, partial);
     hipLaunchKernelGGL(clip_colsum_final_kernel, dim3((unsigned)nsg_cdiv((int64_t)B * C, 256)), dim3(256), 0, s, partial, B, CLIP_SLABS, C, out);
     return nsg_check_launch("clip_colsum");
 }
@@ -295,26 +398,23 @@ int nsg_mse_padded(const float *a, const float *c, int64_t rows, int32_t wa, int
     return nsg_check_launch("mse_padded");
 }
 
-int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_scale, float dq_scale, const float *dz_add,
-                  float *loss_out, float *dz, float *dq, void *workspace, size_t workspace_bytes, void *stream)
+int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_scale, float dq_scale, const void *dz_add,
+                  float *loss_out, void *dz, float *dq, int32_t grad_dtype, void *workspace, size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(z && q && loss_out && n > 0, NSG_E_INVALID, "nsg_vq_losses: bad argument");
+    NSG_REQUIRE(grad_dtype == NSG_F32 || grad_dtype == NSG_BF16, NSG_E_INVALID, "nsg_vq_losses: unknown dtype");
     NSG_REQUIRE(workspace && workspace_bytes >= nsg_reduce_workspace_bytes(n), NSG_E_WORKSPACE, "nsg_vq_losses: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     double *partial = reinterpret_cast<double *>(workspace);
     const float zs = dz_scale * 2.0f / (float)n, qs = dq_scale * 2.0f / (float)n;
-    const bool vec = (n & 3) == 0 && nsg_aligned16(z) && nsg_aligned16(q) && (!dz || nsg_aligned16(dz)) &&
+    const bool vec = (n & 7) == 0 && nsg_aligned16(z) && nsg_aligned16(q) && (!dz || nsg_aligned16(dz)) &&
                      (!dq || nsg_aligned16(dq)) && (!dz_add || nsg_aligned16(dz_add));
-    int nb;
-    if (vec) {
-        nb = ew_blocks(n / 4);
-        if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-        hipLaunchKernelGGL((vq_losses_kernel<4>), dim3(nb), dim3(256), 0, s, z, q, n / 4, zs, qs, dz_add, dz, dq, partial);
-    } else {
-        nb = ew_blocks(n);
-        if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-        hipLaunchKernelGGL((vq_losses_kernel<1>), dim3(nb), dim3(256), 0, s, z, q, n, zs, qs, dz_add, dz, dq, partial);
-    }
+    int nb = ew_blocks(vec ? n / 8 : n);
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+#define NSG_VQL(TG, V) hipLaunchKernelGGL((vq_losses_kernel<TG, V>), dim3(nb), dim3(256), 0, s, z, q, n, zs, qs, (const TG *)dz_add, (TG *)dz, dq, partial)
+    if (grad_dtype == NSG_BF16) { if (vec) NSG_VQL(bf16_t, true); else NSG_VQL(bf16_t, false); }
+    else                        { if (vec) NSG_VQL(float, true);  else NSG_VQL(float, false); }
+#undef NSG_VQL
     hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, s, partial, nb, (double)n, loss_out);
     return nsg_check_launch("vq_losses");
 }

@@ -68,6 +68,22 @@ __device__ __forceinline__ bool nsg_aligned16_dev(const void *p) { return (reint
 static inline int64_t nsg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t nsg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// W consecutive elements <-> floats, W a multiple of the type's 16-byte element count
+template <typename T, int W>
+__device__ __forceinline__ void ldw(const T *p, float *o)
+{
+#pragma unroll
+    for (int k = 0; k < W; k += Elem<T>::N) Elem<T>::load16(p + k, o + k);
+}
+template <typename T, int W>
+__device__ __forceinline__ void stw(T *p, const float *o)
+{
+#pragma unroll
+    for (int k = 0; k < W; k += Elem<T>::N) Elem<T>::store16(p + k, o + k);
+}
+template <typename A, typename B>
+struct Width { static constexpr int W = (sizeof(A) == 2 || sizeof(B) == 2) ? 8 : 4; };
+
 // Division of n < 2^31 by a launch-invariant d >= 1 as one 64-bit multiply + shift (exact: with
 // s = ceil(log2 d) and M = ceil(2^(31+s) / d) the error term n*(M*d - 2^(31+s)) stays below 2^(31+s)).
 struct FastDiv {

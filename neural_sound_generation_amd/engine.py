@@ -98,16 +98,18 @@ def _bn_forward(h, bn: BNParams, training: bool):
 # ------------------------------------------------------------------------------------------------
 # ResBlock   y = relu(x) + BN(conv1x1(relu(BN(conv3x3(relu(x))))))      (src/models.py:145-158)
 # ------------------------------------------------------------------------------------------------
-def resblock_forward(x, P: ResBlockParams, training: bool):
+def resblock_forward(x, P: ResBlockParams, training: bool, out_dtype=None):
+    """x NHWC of the compute dtype (fp32 or bf16: it selects the kernels); out_dtype: storage type of the
+    block's output (default: x's) -- the encoder's last block writes fp32 for the quantiser."""
     B, H, W, D = x.shape
-    d1 = ops.conv_desc(B, H, W, D, D, 3, 1, 1)
-    d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0)
+    d1 = ops.conv_desc(B, H, W, D, D, 3, 1, 1, dtype=x.dtype)
+    d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0, dtype=x.dtype)
     wf1, wd1 = ops.pack_weights(d1, P.conv1.weight)
     wf2, wd2 = ops.pack_weights(d2, P.conv2.weight)
     h1, m1, i1 = _conv_bn(d1, x, wf1, P.conv1, P.bn1, training, flags=NSG_RELU_IN)
     a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
     h2, m2, i2 = _conv_bn(d2, a1, wf2, P.conv2, P.bn2, training)
-    y = ops.bn_apply(h2, m2, i2, P.bn2.weight, P.bn2.bias, relu=False, residual=x, relu_residual=True)
+    y = ops.bn_apply(h2, m2, i2, P.bn2.weight, P.bn2.bias, relu=False, residual=x, relu_residual=True, out_dtype=out_dtype)
     saved = (x, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2)
     return y, saved
 
@@ -137,27 +139,29 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
 # ------------------------------------------------------------------------------------------------
 # Encoder   (src/models.py:164-171)
 # ------------------------------------------------------------------------------------------------
-def encoder_forward(x, P: EncoderParams, training: bool):
-    """x NHWC (B, H, W, 1) -> z_e NHWC (B, H/4, W/4, D)."""
+def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32):
+    """x fp32 NHWC (B, H, W, 1) -> z_e fp32 NHWC (B, H/4, W/4, D).  dtype: storage type of the activations in
+    between (fp32 = parity mode, bf16 = throughput mode); the quantiser input z_e is fp32 in both."""
     B, H, W, _ = x.shape
     D = P.conv0.weight.shape[0]
-    d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1)
+    d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1, dtype=dtype)
     wf0, _ = ops.pack_weights(d0, P.conv0.weight, want_dgrad=False)
     h0, m0, i0 = _conv_bn(d0, x, wf0, P.conv0, P.bn0, training)
     a0 = ops.bn_apply(h0, m0, i0, P.bn0.weight, P.bn0.bias, relu=True)
-    d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1)
+    d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1, dtype=dtype)
     wf3, wd3 = ops.pack_weights(d3, P.conv3.weight)
     e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias)
     r4, s4 = resblock_forward(e3, P.res4, training)
-    ze, s5 = resblock_forward(r4, P.res5, training)
+    ze, s5 = resblock_forward(r4, P.res5, training, out_dtype=torch.float32)
     saved = (x, h0, a0, m0, i0, d0, d3, wd3, s4, s5)
     return ze, saved
 
 
 def encoder_backward(dze, saved, P: EncoderParams, gout=None):
     """Gradients of every encoder parameter, in state_dict order (input gets none: it is data).
-    gout: optional list of 22 preallocated tensors to write into."""
+    dze must have the encoder's compute dtype.  gout: optional list of 22 preallocated tensors to write into."""
     x, h0, a0, m0, i0, d0, d3, wd3, s4, s5 = saved
+    dze = ops.convert(dze, a0.dtype)
     o = gout if gout is not None else [None] * 22
     dr4, g5 = resblock_backward(dze, s5, P.res5, gout=o[14:22] if gout is not None else None)
     de3, g4 = resblock_backward(dr4, s4, P.res4, gout=o[6:14] if gout is not None else None)
@@ -172,16 +176,17 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
 # ------------------------------------------------------------------------------------------------
 # Decoder   (src/models.py:175-184)
 # ------------------------------------------------------------------------------------------------
-def decoder_forward(zq, P: DecoderParams, training: bool):
-    """zq NHWC (B, h, w, D) -> x_tilde NHWC (B, 4h, 4w, 1)."""
+def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32):
+    """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype."""
     B, H, W, D = zq.shape
+    zq = ops.convert(zq, dtype)
     r0, s0 = resblock_forward(zq, P.res0, training)
     r1, s1 = resblock_forward(r0, P.res1, training)
-    dT = ops.conv_desc(B, H, W, D, D, 4, 2, 1, transposed=True)
+    dT = ops.conv_desc(B, H, W, D, D, 4, 2, 1, transposed=True, dtype=dtype)
     wfT, wdT = ops.pack_weights(dT, P.convt3.weight)
     u, m, i = _conv_bn(dT, r1, wfT, P.convt3, P.bn4, training, flags=NSG_RELU_IN)   # decoder.2 ReLU fused into the load
     a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
-    d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True)
+    d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True, dtype=dtype)
     wf6, wd6 = ops.pack_weights(d6, P.convt6.weight)
     xt = ops.conv_forward(d6, a, wf6, P.convt6.bias, flags=NSG_TANH_OUT)  # decoder.7 Tanh fused into the epilogue
     saved = (r1, u, a, m, i, xt, dT, d6, wdT, wd6, s0, s1)

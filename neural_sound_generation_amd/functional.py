@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 from torch.autograd import Function
 
-from . import engine
+from . import engine, ops
 
 
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
@@ -33,19 +33,23 @@ class _Stack(Function):
     """Shared plumbing: subclasses set fwd / bwd / bundle."""
 
     @staticmethod
-    def _run_forward(ctx, fwd, bundle, x, training, params):
+    def _run_forward(ctx, fwd, bundle, x, training, params, dtype):
         _check_float_cuda(x, fwd.__name__)
         ctx.bundle = bundle
         ctx.training = training
-        y, saved = fwd(to_nhwc(x.detach()), bundle, training)
+        ctx.dtype = dtype
+        if fwd is engine.resblock_forward:
+            y, saved = fwd(ops.convert(to_nhwc(x.detach()), dtype), bundle, training, out_dtype=torch.float32)
+        else:
+            y, saved = fwd(to_nhwc(x.detach()), bundle, training, dtype=dtype)
         ctx.saved = saved
         return to_nchw_view(y)
 
 
 class EncoderFn(Function):
     @staticmethod
-    def forward(ctx, x, bundle, training, *params):
-        return _Stack._run_forward(ctx, engine.encoder_forward, bundle, x, training, params)
+    def forward(ctx, x, bundle, training, dtype, *params):
+        return _Stack._run_forward(ctx, engine.encoder_forward, bundle, x, training, params, dtype)
 
     @staticmethod
     def backward(ctx, dz):
@@ -53,13 +57,13 @@ class EncoderFn(Function):
             raise RuntimeError("backward through the encoder in eval() mode is not implemented")
         grads = engine.encoder_backward(to_nhwc(dz), ctx.saved, ctx.bundle)
         ctx.saved = None
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 class DecoderFn(Function):
     @staticmethod
-    def forward(ctx, z, bundle, training, *params):
-        return _Stack._run_forward(ctx, engine.decoder_forward, bundle, z, training, params)
+    def forward(ctx, z, bundle, training, dtype, *params):
+        return _Stack._run_forward(ctx, engine.decoder_forward, bundle, z, training, params, dtype)
 
     @staticmethod
     def backward(ctx, dxt):
@@ -67,30 +71,34 @@ class DecoderFn(Function):
             raise RuntimeError("backward through the decoder in eval() mode is not implemented")
         dz, grads = engine.decoder_backward(to_nhwc(dxt), ctx.saved, ctx.bundle, need_dz=ctx.needs_input_grad[0])
         ctx.saved = None
-        return (to_nchw_view(dz) if dz is not None else None, None, None) + tuple(grads)
+        if dz is not None:
+            dz = to_nchw_view(ops.convert(dz, torch.float32))
+        return (dz, None, None, None) + tuple(grads)
 
 
 class ResBlockFn(Function):
     @staticmethod
-    def forward(ctx, x, bundle, training, *params):
-        return _Stack._run_forward(ctx, engine.resblock_forward, bundle, x, training, params)
+    def forward(ctx, x, bundle, training, dtype, *params):
+        return _Stack._run_forward(ctx, engine.resblock_forward, bundle, x, training, params, dtype)
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("backward through a ResBlock in eval() mode is not implemented")
-        dx, grads = engine.resblock_backward(to_nhwc(dy), ctx.saved, ctx.bundle, need_dx=ctx.needs_input_grad[0])
+        dx, grads = engine.resblock_backward(ops.convert(to_nhwc(dy), ctx.dtype), ctx.saved, ctx.bundle, need_dx=ctx.needs_input_grad[0])
         ctx.saved = None
-        return (to_nchw_view(dx) if dx is not None else None, None, None) + tuple(grads)
+        if dx is not None:
+            dx = to_nchw_view(ops.convert(dx, torch.float32))
+        return (dx, None, None, None) + tuple(grads)
 
 
-def encoder_apply(x, bundle, training):
-    return EncoderFn.apply(x, bundle, training, *engine.encoder_param_list(bundle))
+def encoder_apply(x, bundle, training, dtype=torch.float32):
+    return EncoderFn.apply(x, bundle, training, dtype, *engine.encoder_param_list(bundle))
 
 
-def decoder_apply(z, bundle, training):
-    return DecoderFn.apply(z, bundle, training, *engine.decoder_param_list(bundle))
+def decoder_apply(z, bundle, training, dtype=torch.float32):
+    return DecoderFn.apply(z, bundle, training, dtype, *engine.decoder_param_list(bundle))
 
 
-def resblock_apply(x, bundle, training):
-    return ResBlockFn.apply(x, bundle, training, *engine.resblock_param_list(bundle))
+def resblock_apply(x, bundle, training, dtype=torch.float32):
+    return ResBlockFn.apply(x, bundle, training, dtype, *engine.resblock_param_list(bundle))

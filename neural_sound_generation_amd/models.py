@@ -76,6 +76,8 @@ class VQEmbedding(nn.Module):
 
 
 class ResBlock(nn.Module):
+    compute_dtype = torch.float32   # storage type of the activations inside the block (fp32 or bfloat16)
+
     def __init__(self, dim):
         super().__init__()
         self.block = nn.Sequential(
@@ -91,25 +93,36 @@ class ResBlock(nn.Module):
         # y = relu(x) + block(relu(x)).  The reference also overwrites its argument with relu(x)
         # (nn.ReLU(True), models.py:149); inside VQVAE nothing reads that tensor again, and the
         # fused kernels never mutate their inputs.
-        return Fn.resblock_apply(x, engine.resblock_params(self), self.training)
+        return Fn.resblock_apply(x, engine.resblock_params(self), self.training, self.compute_dtype)
 
 
 class _Encoder(nn.Sequential):
+    compute_dtype = torch.float32
+
     def forward(self, x):
-        return Fn.encoder_apply(x, engine.encoder_params(self), self.training)
+        return Fn.encoder_apply(x, engine.encoder_params(self), self.training, self.compute_dtype)
 
 
 class _Decoder(nn.Sequential):
+    compute_dtype = torch.float32
+
     def forward(self, z):
-        return Fn.decoder_apply(z, engine.decoder_params(self), self.training)
+        return Fn.decoder_apply(z, engine.decoder_params(self), self.training, self.compute_dtype)
 
 
 class VQVAE(nn.Module):
-    def __init__(self, input_dim, dim, z_dim=512, ema_decay=None, n_speakers=None):
+    def __init__(self, input_dim, dim, z_dim=512, ema_decay=None, n_speakers=None, compute_dtype=torch.float32):
         """Reference signature VQVAE(input_dim, dim, z_dim=512) (models.py:162).  Opt-in extensions,
-        neither present in the reference: ema_decay (EMA codebook) and
-        n_speakers (speaker embedding added to the decoder input, BASELINE configs[2])."""
+        neither present in the reference: ema_decay (EMA codebook), n_speakers
+        (speaker embedding added to the decoder input, BASELINE configs[2]) and compute_dtype:
+        torch.float32 (default; the parity mode) or torch.bfloat16 (activations and conv operands in
+        bf16, fp32 accumulation / BatchNorm statistics / quantiser / parameters / optimiser)."""
         super().__init__()
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        if compute_dtype == torch.bfloat16 and dim % 8 != 0:
+            raise ValueError("compute_dtype=bfloat16 needs dim to be a multiple of 8")
+        self.compute_dtype = compute_dtype
         if input_dim != 1:
             raise NotImplementedError("the HIP path implements the speech configuration (input_dim == 1: "
                                       "one-channel 80-bin mel images, src/train.py:115)")
@@ -132,6 +145,8 @@ class VQVAE(nn.Module):
             nn.ConvTranspose2d(dim, input_dim, 4, 2, 1),
             nn.Tanh()
         )
+        self.encoder.compute_dtype = compute_dtype
+        self.decoder.compute_dtype = compute_dtype
         self.n_speakers = n_speakers
         if n_speakers is not None:
             self.speaker_embedding = nn.Embedding(n_speakers, dim)

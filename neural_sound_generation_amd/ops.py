@@ -266,13 +266,13 @@ def conv_wgrad(d: ConvDesc, x, dy, w_shape, flags=0, dw=None, dbias=None, want_b
 # batch norm over [M][C]
 # ------------------------------------------------------------------------------------------------
 def bn_stats(x, C, running_mean=None, running_var=None, eps=BN_EPS, momentum=BN_MOMENTUM):
-    _chk(x, "x")
+    _chk(x, "x", None)
     M = x.numel() // C
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
-    _lib.call("nsg_bn_stats", _p(x), c_int64(M), c_int32(C), c_float(eps), c_float(momentum), _p(mean), _p(invstd),
+    _lib.call("nsg_bn_stats", _p(x), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), c_float(eps), c_float(momentum), _p(mean), _p(invstd),
               _p(running_mean), _p(running_var), _p(ws), c_size_t(nb), _stream())
     return mean, invstd
 
@@ -285,19 +285,25 @@ def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
     return mean, invstd
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_residual=False, out=None):
-    _chk(x, "x")
+def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_residual=False, out=None, out_dtype=None):
+    """out_dtype: storage type of y (default: x's); the residual must have x's type."""
+    _chk(x, "x", None)
+    if residual is not None:
+        _chk(residual, "residual", x.dtype)
     C = mean.numel()
     M = x.numel() // C
-    y = out if out is not None else torch.empty_like(x)
+    y = out if out is not None else torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     _lib.call("nsg_bn_apply", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), _p(y), c_int64(M), c_int32(C),
-              c_int32(1 if relu else 0), c_int32(1 if relu_residual else 0), _stream())
+              c_int32(1 if relu else 0), c_int32(1 if relu_residual else 0), c_int32(nsg_dtype(x.dtype)), c_int32(nsg_dtype(y.dtype)),
+              _stream())
     return y
 
 
 def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out=None, dx_colsum=None):
     """dx_colsum: optional [C] tensor receiving the column sums of dx (= bias gradient of the conv in front)."""
-    _chk(x, "x"); _chk(dy, "dy")
+    _chk(x, "x", None); _chk(dy, "dy", x.dtype)
+    if y_relu is not None:
+        _chk(y_relu, "y_relu", x.dtype)
     C = mean.numel()
     M = x.numel() // C
     dx = out if out is not None else torch.empty_like(x)
@@ -308,7 +314,7 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
     _lib.call("nsg_bn_backward", _p(x), _p(y_relu), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
-              _p(dx_colsum), c_int64(M), c_int32(C), _p(ws), c_size_t(nb), _stream())
+              _p(dx_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return dx, dgamma, dbeta
 
 
@@ -316,9 +322,22 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
 # element-wise / losses / optimiser
 # ------------------------------------------------------------------------------------------------
 def relu_backward_add(a, b, x, out=None):
+    _chk(a, "a", x.dtype)
+    if b is not None:
+        _chk(b, "b", x.dtype)
     dx = out if out is not None else torch.empty_like(x)
-    _lib.call("nsg_relu_backward_add", _p(a), _p(b), _p(x), _p(dx), c_int64(x.numel()), _stream())
+    _lib.call("nsg_relu_backward_add", _p(a), _p(b), _p(x), _p(dx), c_int64(x.numel()), c_int32(nsg_dtype(x.dtype)), _stream())
     return dx
+
+
+def convert(src, dtype, out=None):
+    """Change of storage type (fp32 <-> bf16) by the library's own kernel."""
+    _chk(src, "src", None)
+    if src.dtype == dtype and out is None:
+        return src
+    dst = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    _lib.call("nsg_convert", _p(src), c_int32(nsg_dtype(src.dtype)), _p(dst), c_int32(nsg_dtype(dst.dtype)), c_int64(src.numel()), _stream())
+    return dst
 
 
 def tanh_backward(g, y, out=None):
@@ -333,23 +352,25 @@ def add(a, b, out=None):
     return y
 
 
-def add_per_clip(x, rows, out=None):
-    """x NHWC (B,H,W,C) + rows (B,C) broadcast over each clip's pixels."""
+def add_per_clip(x, rows, out=None, out_dtype=torch.float32):
+    """x fp32 NHWC (B,H,W,C) + rows (B,C) broadcast over each clip's pixels -> y of out_dtype."""
     _chk(x, "x"); _chk(rows, "rows")
     B, C = rows.shape
-    y = out if out is not None else torch.empty_like(x)
-    _lib.call("nsg_add_per_clip", _p(x), _p(rows), _p(y), c_int32(B), c_int64(x.numel() // (B * C)), c_int32(C), _stream())
+    y = out if out is not None else torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.call("nsg_add_per_clip", _p(x), _p(rows), _p(y), c_int32(B), c_int64(x.numel() // (B * C)), c_int32(C),
+              c_int32(nsg_dtype(y.dtype)), _stream())
     return y
 
 
 def clip_colsum(x, B):
     """x NHWC (B,H,W,C) -> (B,C): per-clip sum over pixels."""
-    _chk(x, "x")
+    _chk(x, "x", None)
     C = x.shape[-1]
     out = torch.empty(B, C, dtype=torch.float32, device=x.device)
     nb = _lib.query("nsg_clip_colsum_workspace_bytes", c_int32(B), c_int32(C))
     ws = WS.get(nb, x.device)
-    _lib.call("nsg_clip_colsum", _p(x), c_int32(B), c_int64(x.numel() // (B * C)), c_int32(C), _p(out), _p(ws), c_size_t(nb), _stream())
+    _lib.call("nsg_clip_colsum", _p(x), c_int32(nsg_dtype(x.dtype)), c_int32(B), c_int64(x.numel() // (B * C)), c_int32(C), _p(out), _p(ws),
+              c_size_t(nb), _stream())
     return out
 
 
@@ -364,16 +385,20 @@ def mse_padded(a, c, rows, wa, wc, grad_scale=1.0, want_grad=True):
     return loss, da
 
 
-def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_dq=True):
-    """mean((q - z)^2) and its two one-sided gradients (train.py:131,133)."""
+def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_dq=True, grad_dtype=torch.float32):
+    """mean((q - z)^2) and its two one-sided gradients (train.py:131,133).  z, q, dq fp32; dz (and dz_add,
+    the straight-through gradient coming out of the decoder) in grad_dtype."""
+    _chk(z, "z"); _chk(q, "q")
+    if dz_add is not None:
+        _chk(dz_add, "dz_add", grad_dtype)
     n = z.numel()
     loss = torch.empty(1, dtype=torch.float32, device=z.device)
-    dz = torch.empty_like(z) if want_dz else None
+    dz = torch.empty(z.shape, dtype=grad_dtype, device=z.device) if want_dz else None
     dq = torch.empty_like(z) if want_dq else None
     nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(n))
     ws = WS.get(nb, z.device)
     _lib.call("nsg_vq_losses", _p(z), _p(q), c_int64(n), c_float(dz_scale), c_float(dq_scale), _p(dz_add), _p(loss), _p(dz),
-              _p(dq), _p(ws), c_size_t(nb), _stream())
+              _p(dq), c_int32(nsg_dtype(grad_dtype)), _p(ws), c_size_t(nb), _stream())
     return loss, dz, dq
 
 

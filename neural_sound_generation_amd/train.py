@@ -32,6 +32,7 @@ class FusedTrainStep:
         self.world = nsg_dist.world_size(process_group)
         if self.world > 1:
             nsg_dist.broadcast_flat(self.opt.flat_param, 0, process_group)
+        self.dtype = getattr(model, "compute_dtype", torch.float32)
         self.ema = getattr(model.codebook, "ema_decay", None) is not None
         self.encP = engine.encoder_params(model.encoder)
         self.decP = engine.decoder_params(model.decoder)
@@ -52,7 +53,7 @@ class FusedTrainStep:
             raise RuntimeError("FusedTrainStep needs model.train()")
         x = Fn.to_nhwc(c)
         B, H, T, _ = x.shape
-        ze, es = engine.encoder_forward(x, self.encP, True)
+        ze, es = engine.encoder_forward(x, self.encP, True, dtype=self.dtype)
         D = ze.shape[-1]
         K = self.codebook.shape[0]
         idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True)
@@ -60,8 +61,8 @@ class FusedTrainStep:
         zdec = zq
         if self.spk is not None and g is not None:
             g = g.view(-1).to(torch.int64).contiguous()
-            zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g))
-        xt, ds = engine.decoder_forward(zdec, self.decP, True)
+            zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g), out_dtype=self.dtype)
+        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
         loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
         dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)
@@ -76,11 +77,11 @@ class FusedTrainStep:
         if self.ema:
             # EMA codebook (extension): no codebook gradient; per-code counts and sums of the assigned
             # encoder rows are the statistics every rank contributes (summed over ranks in step())
-            loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False)
+            loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False, grad_dtype=self.dtype)
             s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True)
             self.ema_stats = torch.cat([n, s.view(-1)])       # ONE buffer -> ONE small all-reduce
         else:
-            loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq)
+            loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, grad_dtype=self.dtype)
             self._codebook_grad(idx, dq.view(-1, D), K)
         engine.encoder_backward(dz, es, self.encP, gout=self.g_enc)
         self.last_indices = idx
