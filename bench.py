@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16
 
 
 def flops_per_frame(D: int, K: int) -> float:
@@ -72,6 +73,9 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--z-dim", type=int, default=512)
     ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the parity mode (bit-exact code indices, losses within 1e-5 of the reference); "
+                         "bf16: bf16 activations / conv operands with fp32 accumulation, statistics, quantiser and optimiser")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -90,7 +94,8 @@ def main():
     D, K, T, B = args.dim, args.z_dim, args.frames, args.batch
 
     torch.manual_seed(1)                       # src/main.py:43,71 -- identical init on every rank
-    model = M.VQVAE(1, D, K).to(dev).train()
+    cdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = M.VQVAE(1, D, K, compute_dtype=cdtype).to(dev).train()
     step = FusedTrainStep(model, lr=1e-3, beta=1.0)
     c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
@@ -133,8 +138,11 @@ def main():
                 # command (scripts/pmc_summary.py; PMC cannot be sampled from inside the timed run)
                 traffic = round(json.load(open(pmc))["hbm_bytes_per_launch"] / 1e9, 3)
             if s:
-                roof = {"bound": "mfma", "kernel": "gather_gemm_f32", "achieved": round(s["tflops"], 2),
-                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(s["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+                if args.dtype == "bf16":
+                    traffic = None   # the committed PMC pass is of the fp32 run
+                roof = {"bound": "mfma", "kernel": "gather_gemm (%s operands)" % args.dtype, "achieved": round(s["tflops"], 2),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
                         "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/)", "launches": s["launches"], "avg_launch_ms": round(s["avg_ms"], 4),
                         "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
                         "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3)}
@@ -147,7 +155,7 @@ def main():
         line = {
             "metric": "mel-frames/sec VQ-VAE fwd+bwd+Adam (80-mel x 1024)", "value": round(value, 1), "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: VQVAE(1, dim={D}, z_dim={K}), {B} clips/GPU of 80-mel x {T} frames, "
                                    f"train step (fwd + 3 losses + bwd + Adam{' + grad all-reduce' if world > 1 else ''})",
                        "clips_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",

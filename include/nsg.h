@@ -56,7 +56,8 @@ enum {
     NSG_RELU_IN = 1,   /* apply max(0,.) to the (gathered) input operand while loading it          */
     NSG_TANH_OUT = 2,  /* apply tanh to the result (forward only)                                   */
     NSG_RELU_IN2 = 4,  /* wgrad only: apply max(0,.) to the output-side operand (see nsg_conv_wgrad) */
-    NSG_OUT_F32 = 8    /* forward only: write y as fp32 even when the layer's dtype is bf16          */
+    NSG_OUT_F32 = 8,   /* forward only: write y as fp32 even when the layer's dtype is bf16          */
+    NSG_RELU_OUT = 16  /* forward only: apply max(0,.) to the result (the consumer's leading ReLU)   */
 };
 
 /* Geometry of one convolution layer.  transposed = 0: nn.Conv2d(C_in, C_out, k, stride, pad);
@@ -184,8 +185,10 @@ NSG_API int nsg_bn_eval_stats(const float *running_mean, const float *running_va
 /* (BatchNorm entry points: x / residual / y_relu / dy / dx hold elements of `dtype` (NSG_F32 or NSG_BF16,
  * void* below; nsg_bn_apply may write y in a different y_dtype); statistics, per-channel parameters and all
  * arithmetic are fp32.  bf16 needs C % 8 == 0.) */
-/* y = (x-mean)*invstd*gamma + beta; relu != 0: y = max(0,y); residual != NULL: y += residual
- * (relu_residual != 0: y += max(0,residual) -- the ResBlock's in-place-ReLU'd skip, models.py:149,158). */
+/* y = (x-mean)*invstd*gamma + beta; relu & 1: y = max(0,y); residual != NULL: y += residual
+ * (relu_residual != 0: y += max(0,residual) -- the ResBlock's in-place-ReLU'd skip, models.py:149,158);
+ * relu & 2: y = max(0,y) once more at the very end -- the NEXT ResBlock's leading in-place ReLU
+ * (models.py:149) applied where the tensor is produced instead of where it is consumed. */
 NSG_API int nsg_bn_apply(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
                          const void *residual, void *y, int64_t M, int32_t C, int32_t relu, int32_t relu_residual,
                          int32_t dtype, int32_t y_dtype, void *stream);
@@ -209,8 +212,9 @@ NSG_API int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, c
 NSG_API int nsg_relu_backward_add(const void *a, const void *b, const void *x, void *dx, int64_t n, int32_t dtype,
                                   void *stream);
 
-/* dst = src with a change of storage type (fp32 <-> bf16, round to nearest even). */
-NSG_API int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int64_t n, void *stream);
+/* dst = src (relu != 0: max(0, src)) with a change of storage type (fp32 <-> bf16, round to nearest even). */
+NSG_API int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int64_t n, int32_t relu,
+                        void *stream);
 
 /* dx = g * (1 - y*y): backward of nn.Tanh (models.py:183) from its output y. */
 NSG_API int nsg_tanh_backward(const float *g, const float *y, float *dx, int64_t n, void *stream);

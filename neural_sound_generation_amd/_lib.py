@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libnsg.so")
 NSG_RELU_IN = 1
 NSG_TANH_OUT = 2
 NSG_OUT_F32 = 8
+NSG_RELU_OUT = 16
 NSG_F32 = 0
 NSG_BF16 = 1
 
@@ -56,7 +57,7 @@ _SIGS = {
     "nsg_bn_apply": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, c_int32, _P]),
-    "nsg_convert": (None, [_P, c_int32, _P, c_int32, c_int64, _P]),
+    "nsg_convert": (None, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),
     "nsg_add": (None, [_P, _P, _P, c_int64, _P]),
     "nsg_add_per_clip": (None, [_P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),

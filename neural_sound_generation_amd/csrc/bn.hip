@@ -200,6 +200,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX *__restrict__ x,
                                                        const float *__restrict__ beta, const TX *__restrict__ residual,
                                                        TY *__restrict__ y, int64_t nw, int CW, int relu, int relu_res)
 {
+    // relu bit 0: ReLU right after the affine map; bit 1: ReLU of the final value (after the residual add)
+    const int relu_bn = relu & 1, relu_out = relu & 2;
     constexpr int W = Width<TX, TY>::W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % CW) * W;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX *__restrict__ x,
 #pragma unroll
         for (int e = 0; e < W; ++e) {
             float t = (xv[e] - mean[c + e]) * (invstd[c + e] * gamma[c + e]) + beta[c + e];
-            if (relu) t = fmaxf(t, 0.f);
+            if (relu_bn) t = fmaxf(t, 0.f);
             o[e] = t;
         }
         if (residual) {
@@ -217,6 +219,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX *__restrict__ x,
 #pragma unroll
             for (int e = 0; e < W; ++e) o[e] += relu_res ? fmaxf(rv[e], 0.f) : rv[e];
         }
+        if (relu_out)
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] = fmaxf(o[e], 0.f);
         stw<TY, W>(y + i * W, o);
     }
 }

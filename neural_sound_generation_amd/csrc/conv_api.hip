@@ -346,7 +346,7 @@ static int conv_forward_impl(const nsg_conv_desc *d, const void *x, const void *
         p.B = d->B; p.IH = d->IH; p.IW = d->IW; p.CI = d->C_in;
         p.OH = d->OH; p.OW = d->OW; p.CO = d->C_out;
         p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
-        p.flags = flags & (NSG_RELU_IN | NSG_TANH_OUT);
+        p.flags = flags & (NSG_RELU_IN | NSG_TANH_OUT | NSG_RELU_OUT);
         if (kind == K_CONV) { p.mode = 0; p.RH = d->OH; p.RW = d->OW; }
         else                { p.mode = 1; p.RH = d->IH; p.RW = d->IW; }
         p.M = d->B * p.RH * p.RW;
@@ -388,7 +388,7 @@ int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, const void *
                              float *running_var, void *workspace, size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(d && mean && invstd, NSG_E_INVALID, "nsg_conv_forward_bnstats: null pointer");
-    NSG_REQUIRE(!(flags & NSG_TANH_OUT), NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: statistics are of the linear output");
+    NSG_REQUIRE(!(flags & (NSG_TANH_OUT | NSG_RELU_OUT)), NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: statistics are of the linear output");
     NSG_REQUIRE(workspace && workspace_bytes >= nsg_conv_workspace_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward_bnstats: workspace too small");
     // the tile statistics live at the END of the workspace (the C=1 staging image uses its start)
     const size_t tb = stats_tiles_bytes(d);

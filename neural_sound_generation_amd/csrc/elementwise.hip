@@ -52,18 +52,23 @@ __global__ __launch_bounds__(256) void relu_bwd_add_scalar_kernel(const T *a, co
 
 // dst = src with a change of storage type
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void convert_kernel(const TS *src, TD *dst, int64_t n)
+__global__ __launch_bounds__(256) void convert_kernel(const TS *src, TD *dst, int64_t n, int relu)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        Elem<TD>::put(dst + i, Elem<TS>::get(src + i));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = Elem<TS>::get(src + i);
+        Elem<TD>::put(dst + i, relu ? fmaxf(v, 0.f) : v);
+    }
 }
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void convert_vec_kernel(const TS *src, TD *dst, int64_t nv)
+__global__ __launch_bounds__(256) void convert_vec_kernel(const TS *src, TD *dst, int64_t nv, int relu)
 {
     constexpr int W = Width<TS, TD>::W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
         float v[W];
         ldw<TS, W>(src + i * W, v);
+        if (relu)
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = fmaxf(v[e], 0.f);
         stw<TD, W>(dst + i * W, v);
     }
 }
@@ -294,7 +299,7 @@ int nsg_relu_backward_add(const void *a, const void *b, const void *x, void *dx,
     return nsg_check_launch("relu_bwd_add_kernel");
 }
 
-int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int64_t n, void *stream)
+int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype, int64_t n, int32_t relu, void *stream)
 {
     NSG_REQUIRE(src && dst && n >= 0, NSG_E_INVALID, "nsg_convert: bad argument");
     NSG_REQUIRE((src_dtype == NSG_F32 || src_dtype == NSG_BF16) && (dst_dtype == NSG_F32 || dst_dtype == NSG_BF16), NSG_E_INVALID,
@@ -305,8 +310,8 @@ int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t dst_dtype
     const bool vec = (n % W) == 0 && nsg_aligned16(src) && nsg_aligned16(dst);
 #define NSG_CVT(TS, TD)                                                                                                                   \
     do {                                                                                                                                  \
-        if (vec) hipLaunchKernelGGL((convert_vec_kernel<TS, TD>), dim3(ew_blocks(n / W)), dim3(256), 0, s, (const TS *)src, (TD *)dst, n / W); \
-        else     hipLaunchKernelGGL((convert_kernel<TS, TD>), dim3(ew_blocks(n)), dim3(256), 0, s, (const TS *)src, (TD *)dst, n);          \
+        if (vec) hipLaunchKernelGGL((convert_vec_kernel<TS, TD>), dim3(ew_blocks(n / W)), dim3(256), 0, s, (const TS *)src, (TD *)dst, n / W, relu); \
+        else     hipLaunchKernelGGL((convert_kernel<TS, TD>), dim3(ew_blocks(n)), dim3(256), 0, s, (const TS *)src, (TD *)dst, n, relu);          \
     } while (0)
     if (src_dtype == NSG_F32 && dst_dtype == NSG_BF16) NSG_CVT(float, bf16_t);
     else if (src_dtype == NSG_BF16 && dst_dtype == NSG_F32) NSG_CVT(bf16_t, float);

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     }
     __syncthreads();
     const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
+    const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
     constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
     const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);
     constexpr int NV = BN / EPO;
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
         for (int e = 0; e < EPO; ++e) {
             if (p.bias && col + e < p.CO) v[e] += p.bias[col + e];
             if (tanh_out) v[e] = tanhf(v[e]);
+            if (relu_out) v[e] = fmaxf(v[e], 0.f);
         }
         TO *dst = gout + (size_t)off + col;
         if (vec_store && col + EPO - 1 < p.CO) {

@@ -19,6 +19,8 @@
 static unsigned long long *g_wgrad_stamps = nullptr;   // diagnostics
 static int g_wgrad_diag = 0;
 static int g_wgrad_stagger = 0;
+static int g_wgrad_bf16_native = 1;   // 0: widen bf16 operands to fp32 at staging and use the fp32 MFMA (cross-check path)
+extern "C" NSG_API void nsg_debug_set_wgrad_bf16_native(int on) { g_wgrad_bf16_native = on; }
 extern "C" NSG_API void nsg_debug_set_wgrad_stagger(int units) { g_wgrad_stagger = units; }
 extern "C" NSG_API void nsg_debug_set_wgrad_diag(int on) { g_wgrad_diag = on; }
 extern "C" NSG_API void nsg_debug_set_wgrad_stamp_buffer(unsigned long long *buf) { g_wgrad_stamps = buf; }
@@ -276,6 +278,193 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  The reduction index (pixel) is the ROW
+// of both NHWC operands, so both MFMA operands are needed transposed: lane (r, h) wants 8 consecutive
+// pixels of ONE channel.  ds_read_b64_tr_b16 does that transpose in the LDS read path: per 16-lane
+// group it reads a 4-row x 16-column block of 16-bit elements and hands lane i column i of the 4 rows.
+// LDS tiles are plain [64 pixels][channels] bf16 copies of the rows with a pitch of 2*T + 64 bytes, so
+// the 4 rows of a block land on 4 different 64-byte bank ranges (conflict-free).
+// ------------------------------------------------------------------------------------------------
+constexpr int KPB = 64;   // pixels per chunk (4 MFMA k-steps of 16)
+
+__device__ __forceinline__ s16x4 lds_tr_read(const bf16_t *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_gemm_bf16(const WgradParams p)
+{
+    constexpr int TA = WM * TM * 32;
+    constexpr int TC = WN * TN * 32;
+    constexpr int PP = TA + 32;                          // LDS row pitch in bf16 elements (2*TA + 64 bytes)
+    constexpr int QP = TC + 32;
+    constexpr int PA8 = TA / 8, QC8 = TC / 8;            // 16-byte pieces per pixel row
+    constexpr int PJ = (KPB * PA8 + 255) / 256;
+    constexpr int QJ = (KPB * QC8 + 255) / 256;
+    const bf16_t *__restrict__ gP = reinterpret_cast<const bf16_t *>(p.P);
+    const bf16_t *__restrict__ gQ = reinterpret_cast<const bf16_t *>(p.Q);
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bf16_t *Ps = reinterpret_cast<bf16_t *>(smem);       // [2][KPB][PP]
+    bf16_t *Qs = Ps + 2 * KPB * PP;                      // [2][KPB][QP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int h = lane >> 5;
+    // transposing read: lane = 16*g + 4*q + pp supplies the address of row q, columns 4pp..4pp+3 of its group's block
+    const int g16 = (lane >> 4) & 1;                      // which 16-channel half of the 32-channel tile
+    const int q = (lane >> 2) & 3, pp = lane & 3;
+
+    const int slab = blockIdx.x;
+    const int tap = blockIdx.y;
+    const int ctiles = (p.C + TC - 1) / TC;
+    const int a0 = (blockIdx.z / ctiles) * TA;
+    const int c0 = (blockIdx.z % ctiles) * TC;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    const int mbeg = slab * p.slab_rows;
+    const int mend = min(p.Mp, mbeg + p.slab_rows);
+    const int nchunk = (mend - mbeg + KPB - 1) / KPB;
+
+    v4f rp[PJ], rq[QJ];
+    unsigned okmask = 0;
+    int g_mb = mbeg;
+
+    auto gload = [&]() {
+        const int mb = g_mb;
+        unsigned mk = 0;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const int f = tid + 256 * j;
+            const int pix = f / PA8;
+            const int a8 = (f - pix * PA8) * 8;
+            const int m = mb + pix;
+            const int ok = (pix < KPB) & (m < mend) & ((a0 + a8) < p.A);
+            const size_t off = ok ? ((size_t)m * p.A + a0 + a8) : 0;
+            rp[j] = *reinterpret_cast<const v4f *>(gP + off);
+            mk |= (unsigned)ok << j;
+        }
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const int f = tid + 256 * j;
+            const int pix = f / QC8;
+            const int c8 = (f - pix * QC8) * 8;
+            const int m = mb + pix;
+            const int mm = m < mend ? m : mbeg;
+            const int b = nsg_div(mm, p.div_phw);
+            const int rem = mm - b * (p.PH * p.PW);
+            const int py = nsg_div(rem, p.div_pw);
+            const int px = rem - py * p.PW;
+            const int qy = py * p.stride - p.pad + kh;
+            const int qx = px * p.stride - p.pad + kw;
+            const int ok = (pix < KPB) & (m < mend) & ((c0 + c8) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
+            const size_t off = ok ? (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + c8) : 0;
+            rq[j] = *reinterpret_cast<const v4f *>(gQ + off);
+            mk |= (unsigned)ok << (16 + j);
+        }
+        okmask = mk;
+        g_mb += KPB;
+    };
+    auto relu8 = [](v4f v) {   // bf16 ReLU: a bf16 is negative exactly when its bit pattern is a negative int16
+        s16x8 sv = __builtin_bit_cast(s16x8, v);
+        const s16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        return __builtin_bit_cast(v4f, __builtin_elementwise_max(sv, z8));
+    };
+    auto lstore = [&](int buf) {
+        bf16_t *ps = Ps + buf * KPB * PP;
+        bf16_t *qs = Qs + buf * KPB * QP;
+        const v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const int f = tid + 256 * j;
+            if (f >= KPB * PA8) continue;
+            const int pix = f / PA8, a8 = (f - pix * PA8) * 8;
+            v4f v = (okmask >> j) & 1u ? rp[j] : zero;
+            if (p.relu_p) v = relu8(v);
+            *reinterpret_cast<v4f *>(ps + pix * PP + a8) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const int f = tid + 256 * j;
+            if (f >= KPB * QC8) continue;
+            const int pix = f / QC8, c8 = (f - pix * QC8) * 8;
+            v4f v = (okmask >> (16 + j)) & 1u ? rq[j] : zero;
+            if (p.relu_q) v = relu8(v);
+            *reinterpret_cast<v4f *>(qs + pix * QP + c8) = v;
+        }
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int cur) {
+        // this lane's address inside a (k-step, tile) block: row = 8h + q (+4 for the second half), column = 16*g16 + 4*pp
+        const bf16_t *pbase = Ps + cur * KPB * PP + (8 * h + q) * PP + wr * TM * 32 + 16 * g16 + 4 * pp;
+        const bf16_t *qbase = Qs + cur * KPB * QP + (8 * h + q) * QP + wc * TN * 32 + 16 * g16 + 4 * pp;
+#pragma unroll
+        for (int ks = 0; ks < KPB / 16; ++ks) {
+            s16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const s16x4 lo = lds_tr_read(pbase + (16 * ks) * PP + i * 32);
+                const s16x4 hi = lds_tr_read(pbase + (16 * ks + 4) * PP + i * 32);
+                a[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const s16x4 lo = lds_tr_read(qbase + (16 * ks) * QP + j * 32);
+                const s16x4 hi = lds_tr_read(qbase + (16 * ks + 4) * QP + j * 32);
+                b[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                       acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nchunk > 0) {
+        gload();
+        lstore(0);
+        __syncthreads();
+        for (int ch = 0; ch + 1 < nchunk; ++ch) {
+            const int cur = ch & 1;
+            gload();
+            compute(cur);
+            lstore(cur ^ 1);
+            __syncthreads();
+        }
+        compute((nchunk - 1) & 1);
+    }
+
+    const int ntaps = p.KH * p.KW;
+    const int l31 = lane & 31;
+    float *dst = p.partial + ((size_t)(slab * ntaps + tap) * p.A) * p.C;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + wc * TN * 32 + j * 32 + l31;
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int a = a0 + wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (a < p.A) dst[(size_t)a * p.C + c] = acc[i][j][r];
+            }
+    }
+}
+
 // dst[(a*C + c)*ntaps + t] = sum_slab partial[slab][t][a][c]
 // One thread per output when there are few slabs; otherwise 8 lanes per output split the slabs and
 // the partial sums are added in lane order (fixed order either way: bitwise reproducible).
@@ -356,6 +545,25 @@ int launch_wg1(const WgradParams &p, int nslab, hipStream_t s)
 }
 
 template <int WM, int WN, int TM, int TN>
+int launch_wg_bf16(const WgradParams &p, int nslab, hipStream_t s)
+{
+    constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
+    const size_t lds = (size_t)2 * KPB * ((TA + 32) + (TC + 32)) * sizeof(bf16_t);
+    const int ntaps = p.KH * p.KW;
+    const int tiles = (int)(nsg_cdiv(p.A, TA) * nsg_cdiv(p.C, TC));
+    dim3 grid(nslab, ntaps, tiles);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN>), grid, dim3(256), lds, s, p);
+    return nsg_check_launch("wgrad_gemm_bf16");
+}
+
+template <int WM, int WN, int TM, int TN>
 int launch_wg_diag(const WgradParams &p, int nslab, hipStream_t s)
 {
     constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
@@ -369,7 +577,7 @@ template <int WM, int WN, int TM, int TN>
 int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
 {
     if (p.onehot) return launch_wg1<float, WM, WN, TM, TN, true>(p, nslab, s);   // one-hot: Q (the scattered rows) is fp32
-    if (p.dtype == NSG_BF16) return launch_wg1<bf16_t, WM, WN, TM, TN, false>(p, nslab, s);
+    if (p.dtype == NSG_BF16) return g_wgrad_bf16_native ? launch_wg_bf16<WM, WN, TM, TN>(p, nslab, s) : launch_wg1<bf16_t, WM, WN, TM, TN, false>(p, nslab, s);
     return launch_wg1<float, WM, WN, TM, TN, false>(p, nslab, s);
 }
 

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .ops import NSG_RELU_IN, NSG_TANH_OUT
+from .ops import NSG_RELU_IN, NSG_RELU_OUT, NSG_TANH_OUT
 
 
 @dataclass
@@ -98,19 +98,24 @@ def _bn_forward(h, bn: BNParams, training: bool):
 # ------------------------------------------------------------------------------------------------
 # ResBlock   y = relu(x) + BN(conv1x1(relu(BN(conv3x3(relu(x))))))      (src/models.py:145-158)
 # ------------------------------------------------------------------------------------------------
-def resblock_forward(x, P: ResBlockParams, training: bool, out_dtype=None):
-    """x NHWC of the compute dtype (fp32 or bf16: it selects the kernels); out_dtype: storage type of the
-    block's output (default: x's) -- the encoder's last block writes fp32 for the quantiser."""
-    B, H, W, D = x.shape
-    d1 = ops.conv_desc(B, H, W, D, D, 3, 1, 1, dtype=x.dtype)
-    d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0, dtype=x.dtype)
+def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_out=False):
+    """r = relu(x) NHWC of the compute dtype, ALREADY ReLU'd by its producer: the reference's block starts
+    with an in-place ReLU that overwrites its input (models.py:149), so nothing ever needs the un-ReLU'd
+    tensor and the backward mask (x > 0) equals (r > 0).  Applying that ReLU where the tensor is written
+    removes all ReLU work from the GEMM operand staging.
+    out_dtype: storage type of the output (default: r's) -- the encoder's last block writes fp32 for the
+    quantiser.  relu_out: store relu(y) because the consumer is again a ResBlock / the decoder's ReLU."""
+    B, H, W, D = r.shape
+    d1 = ops.conv_desc(B, H, W, D, D, 3, 1, 1, dtype=r.dtype)
+    d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0, dtype=r.dtype)
     wf1, wd1 = ops.pack_weights(d1, P.conv1.weight)
     wf2, wd2 = ops.pack_weights(d2, P.conv2.weight)
-    h1, m1, i1 = _conv_bn(d1, x, wf1, P.conv1, P.bn1, training, flags=NSG_RELU_IN)
+    h1, m1, i1 = _conv_bn(d1, r, wf1, P.conv1, P.bn1, training)
     a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
     h2, m2, i2 = _conv_bn(d2, a1, wf2, P.conv2, P.bn2, training)
-    y = ops.bn_apply(h2, m2, i2, P.bn2.weight, P.bn2.bias, relu=False, residual=x, relu_residual=True, out_dtype=out_dtype)
-    saved = (x, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2)
+    y = ops.bn_apply(h2, m2, i2, P.bn2.weight, P.bn2.bias, relu=False, residual=r, relu_residual=False, out_dtype=out_dtype,
+                     relu_out=relu_out)
+    saved = (r, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2)
     return y, saved
 
 
@@ -128,7 +133,7 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     dw2, _ = ops.conv_wgrad(d2, a1, dh2, P.conv2.weight.shape, dw=o[4], want_bias=False)
     da1 = ops.conv_dgrad(d2, dh2, wd2)
     dh1, dg1, db1n = ops.bn_backward(h1, a1, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3], dx_colsum=dbias1)
-    dw1, _ = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, flags=NSG_RELU_IN, dw=o[0], want_bias=False)
+    dw1, _ = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, dw=o[0], want_bias=False)   # x is the stored relu(x)
     dx = None
     if need_dx:
         dr = ops.conv_dgrad(d1, dh1, wd1)
@@ -150,8 +155,8 @@ def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32):
     a0 = ops.bn_apply(h0, m0, i0, P.bn0.weight, P.bn0.bias, relu=True)
     d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1, dtype=dtype)
     wf3, wd3 = ops.pack_weights(d3, P.conv3.weight)
-    e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias)
-    r4, s4 = resblock_forward(e3, P.res4, training)
+    e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias, flags=NSG_RELU_OUT)     # stored ReLU'd: its only consumer is a ResBlock
+    r4, s4 = resblock_forward(e3, P.res4, training, relu_out=True)
     ze, s5 = resblock_forward(r4, P.res5, training, out_dtype=torch.float32)
     saved = (x, h0, a0, m0, i0, d0, d3, wd3, s4, s5)
     return ze, saved
@@ -179,12 +184,12 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
 def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32):
     """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype."""
     B, H, W, D = zq.shape
-    zq = ops.convert(zq, dtype)
-    r0, s0 = resblock_forward(zq, P.res0, training)
-    r1, s1 = resblock_forward(r0, P.res1, training)
+    zq = ops.convert(zq, dtype, relu=True)                       # decoder.0's leading ReLU, applied once here
+    r0, s0 = resblock_forward(zq, P.res0, training, relu_out=True)
+    r1, s1 = resblock_forward(r0, P.res1, training, relu_out=True)   # decoder.2 ReLU applied at the producer
     dT = ops.conv_desc(B, H, W, D, D, 4, 2, 1, transposed=True, dtype=dtype)
     wfT, wdT = ops.pack_weights(dT, P.convt3.weight)
-    u, m, i = _conv_bn(dT, r1, wfT, P.convt3, P.bn4, training, flags=NSG_RELU_IN)   # decoder.2 ReLU fused into the load
+    u, m, i = _conv_bn(dT, r1, wfT, P.convt3, P.bn4, training)
     a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
     d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True, dtype=dtype)
     wf6, wd6 = ops.pack_weights(d6, P.convt6.weight)
@@ -203,7 +208,7 @@ def decoder_backward(dxt, saved, P: DecoderParams, need_dz: bool = True, dxt_is_
     da = ops.conv_dgrad(d6, dpre, wd6)
     dbT = o[17] if o[17] is not None else torch.empty(u.shape[-1], dtype=torch.float32, device=u.device)
     du, dg4, dbe4 = ops.bn_backward(u, a, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19], dx_colsum=dbT)
-    dwT, _ = ops.conv_wgrad(dT, r1, du, P.convt3.weight.shape, flags=NSG_RELU_IN, dw=o[16], want_bias=False)
+    dwT, _ = ops.conv_wgrad(dT, r1, du, P.convt3.weight.shape, dw=o[16], want_bias=False)   # r1 is stored ReLU'd
     dr1_pre = ops.conv_dgrad(dT, du, wdT)
     dr1 = ops.relu_backward_add(dr1_pre, None, r1)
     dr0, g1 = resblock_backward(dr1, s1, P.res1, gout=o[8:16] if gout is not None else None)

@@ -39,7 +39,7 @@ class _Stack(Function):
         ctx.training = training
         ctx.dtype = dtype
         if fwd is engine.resblock_forward:
-            y, saved = fwd(ops.convert(to_nhwc(x.detach()), dtype), bundle, training, out_dtype=torch.float32)
+            y, saved = fwd(ops.convert(to_nhwc(x.detach()), dtype, relu=True), bundle, training, out_dtype=torch.float32)
         else:
             y, saved = fwd(to_nhwc(x.detach()), bundle, training, dtype=dtype)
         ctx.saved = saved

@@ -11,7 +11,7 @@ from ctypes import byref, c_float, c_int32, c_int64, c_size_t, c_void_p
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, NSG_RELU_IN, NSG_TANH_OUT, NSG_OUT_F32, NSG_F32, NSG_BF16  # noqa: F401
+from ._lib import ConvDesc, NSG_RELU_IN, NSG_TANH_OUT, NSG_OUT_F32, NSG_RELU_OUT, NSG_F32, NSG_BF16  # noqa: F401
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -285,8 +285,10 @@ def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
     return mean, invstd
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_residual=False, out=None, out_dtype=None):
-    """out_dtype: storage type of y (default: x's); the residual must have x's type."""
+def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_residual=False, out=None, out_dtype=None,
+             relu_out=False):
+    """out_dtype: storage type of y (default: x's); the residual must have x's type.  relu_out: max(0,.) of the
+    final value (the consumer's leading ReLU applied at the producer)."""
     _chk(x, "x", None)
     if residual is not None:
         _chk(residual, "residual", x.dtype)
@@ -294,7 +296,8 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_resid
     M = x.numel() // C
     y = out if out is not None else torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     _lib.call("nsg_bn_apply", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), _p(y), c_int64(M), c_int32(C),
-              c_int32(1 if relu else 0), c_int32(1 if relu_residual else 0), c_int32(nsg_dtype(x.dtype)), c_int32(nsg_dtype(y.dtype)),
+              c_int32((1 if relu else 0) | (2 if relu_out else 0)), c_int32(1 if relu_residual else 0), c_int32(nsg_dtype(x.dtype)),
+              c_int32(nsg_dtype(y.dtype)),
               _stream())
     return y
 
@@ -330,13 +333,14 @@ def relu_backward_add(a, b, x, out=None):
     return dx
 
 
-def convert(src, dtype, out=None):
-    """Change of storage type (fp32 <-> bf16) by the library's own kernel."""
+def convert(src, dtype, out=None, relu=False):
+    """Change of storage type (fp32 <-> bf16), optionally with max(0,.), by the library's own kernel."""
     _chk(src, "src", None)
-    if src.dtype == dtype and out is None:
+    if src.dtype == dtype and out is None and not relu:
         return src
     dst = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
-    _lib.call("nsg_convert", _p(src), c_int32(nsg_dtype(src.dtype)), _p(dst), c_int32(nsg_dtype(dst.dtype)), c_int64(src.numel()), _stream())
+    _lib.call("nsg_convert", _p(src), c_int32(nsg_dtype(src.dtype)), _p(dst), c_int32(nsg_dtype(dst.dtype)), c_int64(src.numel()),
+              c_int32(1 if relu else 0), _stream())
     return dst
 
 

@@ -17,8 +17,11 @@ ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--z-dim", type=int, default=512)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--only", type=str, default="")
+ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
 args = ap.parse_args()
 B, D, K, IT = args.batch, args.dim, args.z_dim, args.iters
+DT = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+PEAK = 2500.0 if args.dtype == "bf16" else 157.3
 dev = "cuda:0"
 
 
@@ -37,7 +40,7 @@ def timeit(fn):
 def report(name, sec, flops=None, bytes_=None):
     s = f"{name:44s} {sec * 1e6:9.1f} us"
     if flops:
-        s += f"  {flops / sec / 1e12:7.1f} TFLOP/s ({flops / sec / 1e12 / 157.3 * 100:4.1f}% f32-MFMA)"
+        s += f"  {flops / sec / 1e12:7.1f} TFLOP/s ({flops / sec / 1e12 / PEAK * 100:4.1f}% {args.dtype}-MFMA)"
     if bytes_:
         s += f"  {bytes_ / sec / 1e9:8.0f} GB/s"
     print(s, flush=True)
@@ -54,19 +57,19 @@ LAYERS = [
 for name, (b, ih, iw, ci, co, k, s, p, tr) in LAYERS:
     if args.only and args.only not in name:
         continue
-    d = ops.conv_desc(b, ih, iw, ci, co, k, s, p, transposed=tr)
-    x = torch.randn(b, ih, iw, ci, device=dev)
-    dy = torch.randn(b, d.OH, d.OW, co, device=dev)
+    d = ops.conv_desc(b, ih, iw, ci, co, k, s, p, transposed=tr, dtype=DT)
+    x = torch.randn(b, ih, iw, ci, device=dev).to(DT if ci > 1 else torch.float32)
+    dy = torch.randn(b, d.OH, d.OW, co, device=dev).to(DT if co > 1 else torch.float32)
     wshape = (ci, co, k, k) if tr else (co, ci, k, k)
     w = torch.randn(*wshape, device=dev) * 0.05
     bias = torch.zeros(co, device=dev)
     wf, wd = ops.pack_weights(d, w)
     fl = ops._gemm_flops(d)
-    y = torch.empty(b, d.OH, d.OW, co, device=dev)
-    dx = torch.empty(b, ih, iw, ci, device=dev)
+    y = torch.empty(b, d.OH, d.OW, co, device=dev, dtype=DT if co > 1 else torch.float32)
+    dx = torch.empty(b, ih, iw, ci, device=dev, dtype=DT if ci > 1 else torch.float32)
     dw = torch.empty(wshape, device=dev)
     db = torch.empty(co, device=dev)
-    io_bytes = 4.0 * (x.numel() + y.numel())
+    io_bytes = float(x.numel() * x.element_size() + y.numel() * y.element_size())
     report(name + " fwd", timeit(lambda: ops.conv_forward(d, x, wf, bias, out=y)), fl, io_bytes)
     report(name + " dgrad", timeit(lambda: ops.conv_dgrad(d, dy, wd, out=dx)), fl, io_bytes)
     report(name + " wgrad(+bias)", timeit(lambda: ops.conv_wgrad(d, x, dy, wshape, dw=dw, dbias=db)), fl, io_bytes)
@@ -82,11 +85,11 @@ if not args.only or "vq" in args.only:
 if not args.only or "bn" in args.only:
     for hh, ww in ((20, 256), (40, 512)):
         M = B * hh * ww
-        x = torch.randn(M, D, device=dev)
-        dy = torch.randn(M, D, device=dev)
+        x = torch.randn(M, D, device=dev).to(DT)
+        dy = torch.randn(M, D, device=dev).to(DT)
         g = torch.ones(D, device=dev)
         bt = torch.zeros(D, device=dev)
-        nb = 4.0 * M * D
+        nb = float(x.element_size()) * M * D
         mean, invstd = ops.bn_stats(x, D)
         y = torch.empty_like(x)
         dx = torch.empty_like(x)
