@@ -77,6 +77,7 @@ def main():
                     help="f32: the parity mode (bit-exact code indices, losses within 1e-5 of the reference); "
                          "bf16: bf16 activations / conv operands with fp32 accumulation, statistics, quantiser and optimiser")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-mode", action="store_true", help="skip the short run of the other compute mode")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 
@@ -93,44 +94,57 @@ def main():
     dev = torch.device("cuda", local)
     D, K, T, B = args.dim, args.z_dim, args.frames, args.batch
 
-    torch.manual_seed(1)                       # src/main.py:43,71 -- identical init on every rank
-    cdtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = M.VQVAE(1, D, K, compute_dtype=cdtype).to(dev).train()
-    step = FusedTrainStep(model, lr=1e-3, beta=1.0)
-    c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    def run_mode(dtype_name, steps, warmup, use_timer):
+        """Time `steps` training steps of the given compute mode; returns (value, ms_per_step, losses, timer summary)."""
+        torch.manual_seed(1)                       # src/main.py:43,71 -- identical init on every rank
+        cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        model = M.VQVAE(1, D, K, compute_dtype=cdtype).to(dev).train()
+        step = FusedTrainStep(model, lr=1e-3, beta=1.0)
+        c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
-    def sync():
+        def sync():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            step.step(c)
+        timer = None
+        if use_timer:
+            timer = ops.KernelTimer()
+            ops.KERNEL_TIMER = timer
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses = step.step(c)
+        sync()
+        elapsed = time.perf_counter() - t0
+        ops.KERNEL_TIMER = None
         if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        value = world * B * T * steps / elapsed
+        summ = timer.summary().get("gather_gemm_f32") if timer is not None else None
+        del step, model
+        torch.cuda.empty_cache()
+        return value, elapsed / steps * 1e3, [float(x.item()) for x in losses], summ
 
-    for _ in range(args.warmup):
-        step.step(c)
-    timer = None
-    if not args.no_kernel_timer:
-        timer = ops.KernelTimer()
-        ops.KERNEL_TIMER = timer
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = step.step(c)
-    sync()
-    elapsed = time.perf_counter() - t0
-    ops.KERNEL_TIMER = None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    frames_total = world * B * T * args.steps
-    value = frames_total / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
-    loss_triple = [float(x.item()) for x in losses]
+    value, ms_per_step, loss_triple, s = run_mode(args.dtype, args.steps, args.warmup, not args.no_kernel_timer)
+    other = None
+    if not args.no_second_mode:
+        # the other compute mode, same shapes, a short run: fp32 = parity mode, bf16 = throughput mode
+        od = "bf16" if args.dtype == "f32" else "f32"
+        ov, oms, ol, osum = run_mode(od, max(3, args.steps // 4), 2, not args.no_kernel_timer)
+        other = {"dtype": od, "value": round(ov, 1), "unit": "mel-frames/s", "ms_per_step": round(oms, 3), "losses": ol}
+        if osum:
+            opeak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
+            other["roofline"] = {"bound": "mfma", "kernel": "gather_gemm (%s operands)" % od, "achieved": round(osum["tflops"], 2),
+                                 "peak": opeak, "unit": "TFLOP/s", "frac": round(osum["tflops"] / opeak, 4)}
 
     if rank == 0:
         roof = None
-        if timer is not None:
-            s = timer.summary().get("gather_gemm_f32")
+        if s is not None:
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
             if os.path.exists(pmc) and (D, K, B, T) == (128, 512, 64, 1024):
@@ -162,7 +176,7 @@ def main():
                        "per_gpu_value": round(value / world, 1),
                        "algorithmic_tflops": round(value * flops_per_frame(D, K) / 1e12, 2),
                        "losses": loss_triple},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "other_mode": other,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -113,12 +113,19 @@ __device__ __forceinline__ void block_sum_store(double part, double *dst)
     }
 }
 
+// one wave: each lane sums a strided share of the block partials, then a fixed-order lane walk
 __global__ void final_mean_kernel(const double *partial, int n, double denom, float *out)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < n; ++i) t += partial[i];
-        out[0] = (float)(t / denom);
+    __shared__ double red[64];
+    const int lane = threadIdx.x;
+    double t = 0.0;
+    for (int i = lane; i < n; i += 64) t += partial[i];
+    red[lane] = t;
+    __syncthreads();
+    if (lane == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 64; ++i) s += red[i];
+        out[0] = (float)(s / denom);
     }
 }
 
