@@ -130,12 +130,19 @@ NSG_API int nsg_vq_ema_update(float *e, float *ema_n, float *ema_s, const float 
  * Convolutions                                            src/models.py:150,153,165,168,179,182
  * ------------------------------------------------------------------------------------------- */
 
-/* ELEMENTS (of d->dtype) in each packed weight image (forward image, dgrad image). */
+/* ELEMENTS (of d->dtype) to allocate for each packed weight image (forward image, dgrad image).
+ * (The two single-channel layers keep one of their images as fp32 [C][16] for the stencil kernels whatever
+ * d->dtype is; the count accounts for that.) */
 NSG_API size_t nsg_packed_weight_floats(const nsg_conv_desc *d);
 
 /* Re-pack reference-layout weights into the two [tap][n][c] images the GEMM kernels stream:
  * w_fwd for nsg_conv_forward, w_dgrad for nsg_conv_dgrad (either may be NULL to skip it). */
 NSG_API int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, void *w_fwd, void *w_dgrad, void *stream);
+
+/* The same for n layers in ONE kernel launch (a training step re-packs every layer after the optimiser
+ * step): descs[n], w[n], w_fwd[n], w_dgrad[n] are host arrays; NULL image pointers are skipped. */
+NSG_API int nsg_pack_conv_weights_batch(int32_t n, const nsg_conv_desc *descs, const float *const *w,
+                                        void *const *w_fwd, void *const *w_dgrad, void *stream);
 
 /* Workspace bytes for forward/dgrad (C == 1 layers stage im2col/col2im images) and wgrad (split-K slabs). */
 NSG_API size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d);
@@ -193,14 +200,16 @@ NSG_API int nsg_bn_apply(const void *x, const float *mean, const float *invstd, 
                          const void *residual, void *y, int64_t M, int32_t C, int32_t relu, int32_t relu_residual,
                          int32_t dtype, int32_t y_dtype, void *stream);
 
-/* Backward of the call above with respect to x, gamma, beta.  y_relu: the forward OUTPUT when
- * relu != 0 was used (its sign is the ReLU mask), else NULL.  dgamma/dbeta [C] overwritten.
+/* Backward of the call above with respect to x, gamma, beta.  When the forward used relu & 1, the ReLU mask
+ * comes from ONE of: relu_beta = the forward's beta [C] (the mask (x-mean)*(invstd*gamma)+beta > 0 is then
+ * re-derived from x with the forward's own arithmetic and y_relu is not read -- one tensor less of traffic),
+ * or y_relu = the forward OUTPUT (its sign is the mask).  Both NULL: no ReLU.  dgamma/dbeta [C] overwritten.
  * dx_colsum [C] or NULL: column sums of dx, i.e. the bias gradient of the convolution that feeds
  * this BatchNorm (autograd of nn.Conv2d's bias at src/models.py:150,153,165,179), produced by the
  * kernel that writes dx instead of a second pass over it. */
 NSG_API int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const float *mean,
-                            const float *invstd, const float *gamma, void *dx, float *dgamma, float *dbeta,
-                            float *dx_colsum, int64_t M, int32_t C, int32_t dtype, void *workspace,
+                            const float *invstd, const float *gamma, const float *relu_beta, void *dx, float *dgamma,
+                            float *dbeta, float *dx_colsum, int64_t M, int32_t C, int32_t dtype, void *workspace,
                             size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

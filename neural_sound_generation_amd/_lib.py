@@ -46,6 +46,7 @@ _SIGS = {
     "nsg_vq_ema_update": (None, [_P, _P, _P, _P, _P, c_int32, c_int32, c_float, c_float, _P, _P]),
     "nsg_packed_weight_floats": (c_size_t, [_D]),
     "nsg_pack_conv_weights": (None, [_D, _P, _P, _P, _P]),
+    "nsg_pack_conv_weights_batch": (None, [c_int32, _P, _P, _P, _P, _P]),
     "nsg_conv_workspace_bytes": (c_size_t, [_D]),
     "nsg_conv_forward": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_conv_forward_bnstats": (None, [_D, _P, _P, _P, _P, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -55,7 +56,7 @@ _SIGS = {
     "nsg_bn_stats": (None, [_P, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_bn_eval_stats": (None, [_P, _P, c_int32, c_float, _P, _P, _P]),
     "nsg_bn_apply": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
-    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, c_int32, _P]),
     "nsg_convert": (None, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),

@@ -4,9 +4,11 @@
 // Activations may be stored fp32 or bf16 (templates below); all arithmetic, statistics and
 // per-channel parameters are fp32.
 //
-// Statistics are formed per slab of rows as (count, mean, M2 about the slab mean) and merged with
-// Chan's parallel formula in double, in slab order: no E[x^2]-E[x]^2 cancellation and bitwise
+// Statistics are formed per slab of rows as (count, mean, M2 about the slab mean) in one pass about a
+// pivot row, and pooled in double in slab order: no E[x^2]-E[x]^2 cancellation and bitwise
 // reproducible (no atomics).
+// The backward of a BatchNorm that was followed by a fused ReLU re-derives the ReLU mask from x itself
+// ((x-mean)*(invstd*gamma)+beta > 0, the forward's own expression) instead of reading the stored output.
 #include "nsg_common.h"
 
 namespace {
@@ -29,14 +31,15 @@ inline SlabGeom slab_geom(int64_t M)
 }
 
 // threads: cg = tid % CW owns channels W*cg .. W*cg+W-1, rg = tid / CW strides over the slab's rows.
-// partial[slab] = { mean[C], M2[C] } (count is implied by the slab geometry)
+// partial[slab] = { mean[C], M2[C] } (count is implied by the slab geometry).
+// ONE pass: sums of d = v - pivot and d^2 with pivot = the slab's first row (a sample of the column, so
+// |mean - pivot| is of the order of the column's spread and M2 = S2 - S1^2/n loses no more than a few bits).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T *__restrict__ x, int64_t M, int C, int slab_rows,
                                                                float *__restrict__ partial)
 {
     constexpr int W = Elem<T>::N;
-    __shared__ float red[256 * W];
-    __shared__ float smean[1024];
+    __shared__ float red[2 * 256 * W];
     const int CW = C / W;
     const int rgroups = 256 / CW;
     const int tid = threadIdx.x;
@@ -46,57 +49,40 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T *__restri
     const int64_t r1 = min(M, r0 + slab_rows);
     const int n = (int)(r1 - r0);
 
-    float s[W];
-#pragma unroll
-    for (int e = 0; e < W; ++e) s[e] = 0.f;
-    if (active)
-        for (int64_t r = r0 + rg; r < r1; r += rgroups) {
-            float v[W];
-            ldw<T, W>(x + r * C + cg * W, v);
-#pragma unroll
-            for (int e = 0; e < W; ++e) s[e] += v[e];
-        }
-    if (active)
-#pragma unroll
-        for (int e = 0; e < W; ++e) red[(rg * CW + cg) * W + e] = s[e];
-    __syncthreads();
-    if (tid < CW) {
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            float t = 0.f;
-            for (int g = 0; g < rgroups; ++g) t += red[(g * CW + tid) * W + e];
-            smean[tid * W + e] = t / (float)n;
-        }
-    }
-    __syncthreads();
+    float pv[W];
     if (active) {
-        float mu[W], q[W];
+        float s1[W], s2[W];
+        ldw<T, W>(x + r0 * C + cg * W, pv);
 #pragma unroll
-        for (int e = 0; e < W; ++e) { mu[e] = smean[cg * W + e]; q[e] = 0.f; }
+        for (int e = 0; e < W; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll 4
         for (int64_t r = r0 + rg; r < r1; r += rgroups) {
             float v[W];
             ldw<T, W>(x + r * C + cg * W, v);
 #pragma unroll
-            for (int e = 0; e < W; ++e) { const float d = v[e] - mu[e]; q[e] += d * d; }
+            for (int e = 0; e < W; ++e) { const float d = v[e] - pv[e]; s1[e] += d; s2[e] += d * d; }
         }
 #pragma unroll
-        for (int e = 0; e < W; ++e) red[(rg * CW + cg) * W + e] = q[e];
+        for (int e = 0; e < W; ++e) { red[(rg * CW + cg) * W + e] = s1[e]; red[256 * W + (rg * CW + cg) * W + e] = s2[e]; }
     }
     __syncthreads();
     if (tid < CW) {
         float *dst = partial + (size_t)blockIdx.x * 2 * C;
+        const float inv_n = 1.f / (float)n;
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            float t = 0.f;
-            for (int g = 0; g < rgroups; ++g) t += red[(g * CW + tid) * W + e];
-            dst[tid * W + e] = smean[tid * W + e];
-            dst[C + tid * W + e] = t;
+            float t1 = 0.f, t2 = 0.f;
+            for (int g = 0; g < rgroups; ++g) { t1 += red[(g * CW + tid) * W + e]; t2 += red[256 * W + (g * CW + tid) * W + e]; }
+            dst[tid * W + e] = pv[e] + t1 * inv_n;
+            dst[C + tid * W + e] = fmaxf(t2 - t1 * t1 * inv_n, 0.f);
         }
     }
 }
 
-// 32 lanes per channel: lane j merges its contiguous run of slabs (Chan, double), lane 0 then merges
-// the 32 partial results in lane order.  Fixed order -> bitwise reproducible.
+// 32 lanes per channel.  Lane j owns a contiguous run of slabs and forms (n, mean, M2) of the run in double as
+//   n = sum n_s,  mean = sum n_s m_s / n,  M2 = sum ( q_s + n_s (m_s - mean)^2 )
+// (the pooled-variance identity; no division chain), lane 0 then pools the 32 runs the same way, in lane
+// order.  Fixed order -> bitwise reproducible.
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ partial, int nslab, int slab_rows, int64_t M,
                                                              int C, float eps, float momentum, float *mean, float *invstd,
                                                              float *running_mean, float *running_var)
@@ -109,31 +95,29 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__rest
     if (c < C) {
         const int per = (nslab + 31) / 32;
         const int s0 = j * per, s1 = min(nslab, s0 + per);
+        double t = 0.0;
         for (int s = s0; s < s1; ++s) {
             const int64_t r0 = (int64_t)s * slab_rows;
             const double ns = (double)(min(M, r0 + slab_rows) - r0);
-            const double ms = partial[(size_t)s * 2 * C + c];
-            const double qs = partial[(size_t)s * 2 * C + C + c];
-            const double tot = n + ns;
-            const double delta = ms - mu;
-            mu += delta * ns / tot;
-            m2 += qs + delta * delta * n * ns / tot;
-            n = tot;
+            n += ns;
+            t += ns * (double)partial[(size_t)s * 2 * C + c];
+        }
+        if (n > 0.0) mu = t / n;
+        for (int s = s0; s < s1; ++s) {
+            const int64_t r0 = (int64_t)s * slab_rows;
+            const double ns = (double)(min(M, r0 + slab_rows) - r0);
+            const double dl = (double)partial[(size_t)s * 2 * C + c] - mu;
+            m2 += (double)partial[(size_t)s * 2 * C + C + c] + ns * dl * dl;
         }
     }
     sn[tid] = n; smu[tid] = mu; sm2[tid] = m2;
     __syncthreads();
     if (j != 0 || c >= C) return;
-    n = 0.0; mu = 0.0; m2 = 0.0;
-    for (int k = 0; k < 32; ++k) {
-        const double ns = sn[tid + k];
-        if (ns == 0.0) continue;
-        const double tot = n + ns;
-        const double delta = smu[tid + k] - mu;
-        mu += delta * ns / tot;
-        m2 += sm2[tid + k] + delta * delta * n * ns / tot;
-        n = tot;
-    }
+    double nt = 0.0, t = 0.0;
+    for (int k = 0; k < 32; ++k) { nt += sn[tid + k]; t += sn[tid + k] * smu[tid + k]; }
+    mu = t / nt;
+    m2 = 0.0;
+    for (int k = 0; k < 32; ++k) { const double dl = smu[tid + k] - mu; m2 += sm2[tid + k] + sn[tid + k] * dl * dl; }
     const double var_b = m2 / (double)M;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var_b + (double)eps));
@@ -230,7 +214,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX *__restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T *__restrict__ x, const T *__restrict__ yrelu,
                                                              const T *__restrict__ dy, const float *__restrict__ mean,
-                                                             const float *__restrict__ invstd, int64_t M, int C,
+                                                             const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                             const float *__restrict__ relu_beta, int64_t M, int C,
                                                              int slab_rows, float *__restrict__ partial)
 {
     constexpr int W = Elem<T>::N;
@@ -243,15 +228,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T *__restrict
     const int64_t r0 = (int64_t)blockIdx.x * slab_rows;
     const int64_t r1 = min(M, r0 + slab_rows);
     if (active) {
-        float s1[W], s2[W], mu[W], is[W];
+        float s1[W], s2[W], mu[W], is[W], sc[W], be[W];
 #pragma unroll
-        for (int e = 0; e < W; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = mean[cg * W + e]; is[e] = invstd[cg * W + e]; }
+        for (int e = 0; e < W; ++e) {
+            s1[e] = 0.f; s2[e] = 0.f; mu[e] = mean[cg * W + e]; is[e] = invstd[cg * W + e];
+            sc[e] = relu_beta ? is[e] * gamma[cg * W + e] : 0.f;
+            be[e] = relu_beta ? relu_beta[cg * W + e] : 0.f;
+        }
         for (int64_t r = r0 + rg; r < r1; r += rgroups) {
             const size_t o = (size_t)r * C + cg * W;
             float g[W], xv[W];
             ldw<T, W>(dy + o, g);
             ldw<T, W>(x + o, xv);
-            if (yrelu) {
+            if (relu_beta) {          // the forward's own expression (bn_apply_kernel): same rounding, same decision
+#pragma unroll
+                for (int e = 0; e < W; ++e) g[e] = ((xv[e] - mu[e]) * sc[e] + be[e]) > 0.f ? g[e] : 0.f;
+            } else if (yrelu) {
                 float yv[W];
                 ldw<T, W>(yrelu + o, yv);
 #pragma unroll
@@ -307,8 +299,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
                                                            const T *__restrict__ dy, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                            const float *__restrict__ dgamma, const float *__restrict__ dbeta,
-                                                           T *__restrict__ dx, int64_t M, int C, int slab_rows, float inv_m,
-                                                           float *__restrict__ partial)
+                                                           const float *__restrict__ relu_beta, T *__restrict__ dx, int64_t M, int C,
+                                                           int slab_rows, float inv_m, float *__restrict__ partial)
 {
     constexpr int W = Elem<T>::N;
     __shared__ float red[256 * W];
@@ -323,18 +315,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
 #pragma unroll
     for (int e = 0; e < W; ++e) s[e] = 0.f;
     if (active) {
-        float mu[W], is[W], sc[W], dg[W], db[W];
+        float mu[W], is[W], sc[W], dg[W], db[W], fs[W], be[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
             const int c = cg * W + e;
             mu[e] = mean[c]; is[e] = invstd[c]; sc[e] = gamma[c] * is[e]; dg[e] = dgamma[c] * inv_m; db[e] = dbeta[c] * inv_m;
+            fs[e] = is[e] * gamma[c];                  // the forward's scale, in the forward's operand order
+            be[e] = relu_beta ? relu_beta[c] : 0.f;
         }
         for (int64_t r = r0 + rg; r < r1; r += rgroups) {
             const size_t o = (size_t)r * C + cg * W;
             float g[W], xv[W], d[W];
             ldw<T, W>(dy + o, g);
             ldw<T, W>(x + o, xv);
-            if (yrelu) {
+            if (relu_beta) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) g[e] = ((xv[e] - mu[e]) * fs[e] + be[e]) > 0.f ? g[e] : 0.f;
+            } else if (yrelu) {
                 float yv[W];
                 ldw<T, W>(yrelu + o, yv);
 #pragma unroll
@@ -470,8 +467,8 @@ int nsg_bn_apply(const void *x, const float *mean, const float *invstd, const fl
 }
 
 int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd,
-                    const float *gamma, void *dx, float *dgamma, float *dbeta, float *dx_colsum, int64_t M, int32_t C,
-                    int32_t dtype, void *workspace, size_t workspace_bytes, void *stream)
+                    const float *gamma, const float *relu_beta, void *dx, float *dgamma, float *dbeta, float *dx_colsum,
+                    int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(x && dy && mean && invstd && gamma && dx && dgamma && dbeta, NSG_E_INVALID, "nsg_bn_backward: null pointer");
     int rc = check_mc("nsg_bn_backward", M, C, dtype);
@@ -485,17 +482,17 @@ int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const flo
     const float inv_m = 1.0f / (float)M;
     if (dtype == NSG_BF16) {
         typedef bf16_t T;
-        hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, M, C, g.rows, partial);
+        hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
         hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
         // the stage-1 partials have been consumed by bn_bwd_final (stream order): the buffer is reused for the dx column sums
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
-                           dgamma, dbeta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
+                           dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
     } else {
         typedef float T;
-        hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, M, C, g.rows, partial);
+        hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
         hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
-                           dgamma, dbeta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
+                           dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
     }
     if (dx_colsum) hipLaunchKernelGGL(slab_sum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dx_colsum);
     return nsg_check_launch("bn_backward");

@@ -1,5 +1,5 @@
 // Convolution entry points: geometry checks, weight re-packing, the single-channel (C == 1)
-// im2col / col2im stagings, bias gradients, and dispatch onto the two GEMM kernels.
+// col2im staging, bias gradients, and dispatch onto the two GEMM kernels.
 // Reference call sites: src/models.py:150,153,165,168 (nn.Conv2d), :179,182 (nn.ConvTranspose2d).
 #include "nsg_common.h"
 
@@ -7,50 +7,38 @@
 static unsigned long long *g_debug_stamps = nullptr;
 extern "C" NSG_API void nsg_debug_set_stamp_buffer(unsigned long long *buf) { g_debug_stamps = buf; }
 
+// stencil_c1.hip
+bool nsg_c1_stencil_supported(int C);
+size_t nsg_c1_stencil_wgrad_workspace_bytes(int C);
+int nsg_launch_c1_stencil_fwd(const float *img, const float *w, const float *bias, void *out, int out_dtype, int B, int LH, int LW,
+                              int HH, int WW, int C, hipStream_t s);
+int nsg_launch_c1_stencil_wgrad(const float *img, const void *t, int t_dtype, int relu_t, float *dw, float *colsum, int B, int LH,
+                                int LW, int HH, int WW, int C, void *ws, size_t ws_bytes, hipStream_t s);
+
 namespace {
 
-// dst[(t*NN + n)*CC + c] = src[n*sn + c*sc + (flip ? T-1-t : t)]
-template <typename TO>
-__global__ void pack_w_kernel(const float *__restrict__ src, TO *__restrict__ dst, int T, int NN, int CC, int sn, int sc, int flip)
+// One weight re-pack:  dst[(t*NN + n)*CC + c] = src[n*sn + c*sc + (flip ? T-1-t : t)]  (dst fp32 or bf16)
+struct PackJob {
+    const float *src;
+    void *dst;
+    int T, NN, CC, sn, sc, flip, bf16;
+};
+constexpr int PACK_MAX_JOBS = 32;
+struct PackJobs {
+    PackJob job[PACK_MAX_JOBS];
+};
+// blockIdx.y = job: every packed image of a training step in ONE launch
+__global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
 {
-    const int64_t total = (int64_t)T * NN * CC;
+    const PackJob j = jobs.job[blockIdx.y];
+    const int64_t total = (int64_t)j.T * j.NN * j.CC;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CC);
-        const int n = (int)((i / CC) % NN);
-        const int t = (int)(i / ((int64_t)CC * NN));
-        Elem<TO>::put(dst + i, src[(size_t)n * sn + (size_t)c * sc + (flip ? T - 1 - t : t)]);
-    }
-}
-
-// img [B][HH][WW] (one channel) -> patches [B][LH][LW][16], tap = kh*4+kw, pixel (2ly+kh-1, 2lx+kw-1)
-// (LH,LW) = floor(HH/2), floor(WW/2): the 4/2/1 convolution's output grid
-template <typename TO>
-__global__ void im2col_c1_kernel(const float *__restrict__ img, TO *__restrict__ patches, int B, int LH, int LW, int HH, int WW)
-{
-    const int64_t total = (int64_t)B * LH * LW * 4;  // one thread per (pixel, kh)
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kh = (int)(i & 3);
-        const int64_t pix = i >> 2;
-        const int lx = (int)(pix % LW);
-        const int ly = (int)((pix / LW) % LH);
-        const int b = (int)(pix / ((int64_t)LW * LH));
-        const int y = 2 * ly + kh - 1;
-        v4f v = {0.f, 0.f, 0.f, 0.f};
-        if (y >= 0 && y < HH) {
-            const float *row = img + ((size_t)b * HH + y) * WW;
-            const int x0 = 2 * lx - 1;
-            if (x0 >= 0) v.x = row[x0];
-            v.y = row[x0 + 1];
-            if (x0 + 2 < WW) v.z = row[x0 + 2];
-            if (x0 + 3 < WW) v.w = row[x0 + 3];
-        }
-        if constexpr (sizeof(TO) == 4) {
-            *reinterpret_cast<v4f *>(patches + i * 4) = v;
-        } else {
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            v2u pk = {(unsigned)nsg_f2bf(v.x) | ((unsigned)nsg_f2bf(v.y) << 16), (unsigned)nsg_f2bf(v.z) | ((unsigned)nsg_f2bf(v.w) << 16)};
-            *reinterpret_cast<v2u *>(patches + i * 4) = pk;
-        }
+        const int c = (int)(i % j.CC);
+        const int n = (int)((i / j.CC) % j.NN);
+        const int t = (int)(i / ((int64_t)j.CC * j.NN));
+        const float v = j.src[(size_t)n * j.sn + (size_t)c * j.sc + (j.flip ? j.T - 1 - t : t)];
+        if (j.bf16) reinterpret_cast<bf16_t *>(j.dst)[i] = nsg_f2bf(v);
+        else        reinterpret_cast<float *>(j.dst)[i] = v;
     }
 }
 
@@ -111,28 +99,43 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const TI *__restric
         __syncthreads();
     }
 }
-// vector form of the above for C % 4 == 0: thread (cg, rg) owns 4 channels of every rgroups-th row
-__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float *__restrict__ x, int64_t M, int C, int slab_rows,
+// vector form of the above for C % W == 0 (W = elements per 16 bytes): thread (cg, rg) owns W channels of every rgroups-th row
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const TI *__restrict__ x, int64_t M, int C, int slab_rows,
                                                                  float *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) float red[256 * 4];
-    const int C4 = C >> 2;
+    constexpr int W = Elem<TI>::N;
+    __shared__ __attribute__((aligned(16))) float red[256 * W];
+    const int CW = C / W;
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * slab_rows;
     const int64_t r1 = min(M, r0 + slab_rows);
-    for (int cb = 0; cb < C4; cb += 256) {          // C <= 1024 -> a single pass
-        const int cw = min(256, C4 - cb);
+    for (int cb = 0; cb < CW; cb += 256) {          // C <= 256*W -> a single pass
+        const int cw = min(256, CW - cb);
         const int rgroups = 256 / cw;
         const int cg = tid % cw, rg = tid / cw;
-        v4f s = {0.f, 0.f, 0.f, 0.f};
-        if (rg < rgroups)
-            for (int64_t r = r0 + rg; r < r1; r += rgroups) s += *reinterpret_cast<const v4f *>(x + r * C + (cb + cg) * 4);
-        if (rg < rgroups) *reinterpret_cast<v4f *>(red + (rg * cw + cg) * 4) = s;
+        float s[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) s[e] = 0.f;
+        if (rg < rgroups) {
+#pragma unroll 4
+            for (int64_t r = r0 + rg; r < r1; r += rgroups) {
+                float v[W];
+                Elem<TI>::load16(x + r * C + (cb + cg) * W, v);
+#pragma unroll
+                for (int e = 0; e < W; ++e) s[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) red[(rg * cw + cg) * W + e] = s[e];
+        }
         __syncthreads();
         if (tid < cw) {
-            v4f t = {0.f, 0.f, 0.f, 0.f};
-            for (int g = 0; g < rgroups; ++g) t += *reinterpret_cast<const v4f *>(red + (g * cw + tid) * 4);
-            *reinterpret_cast<v4f *>(partial + (size_t)blockIdx.x * C + (cb + tid) * 4) = t;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                float t = 0.f;
+                for (int g = 0; g < rgroups; ++g) t += red[(g * cw + tid) * W + e];
+                partial[(size_t)blockIdx.x * C + (cb + tid) * W + e] = t;
+            }
         }
         __syncthreads();
     }
@@ -174,10 +177,12 @@ int colsum(const void *x, int dtype, int64_t M, int C, float *out, void *ws, hip
 {
     const CsGeom g = cs_geom(M);
     float *partial = reinterpret_cast<float *>(ws);
-    if (dtype == NSG_BF16)
+    if (dtype == NSG_BF16 && C % 8 == 0 && nsg_aligned16(x))
+        hipLaunchKernelGGL((colsum_partial_vec_kernel<bf16_t>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), M, C, g.rows, partial);
+    else if (dtype == NSG_BF16)
         hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), M, C, g.rows, partial);
     else if (C % 4 == 0 && nsg_aligned16(x))
-        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const float *>(x), M, C, g.rows, partial);
+        hipLaunchKernelGGL((colsum_partial_vec_kernel<float>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const float *>(x), M, C, g.rows, partial);
     else
         hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const float *>(x), M, C, g.rows, partial);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, out);
@@ -210,8 +215,8 @@ int classify(const nsg_conv_desc *d, const char *fn)
         if (d->OH != (d->IH + 2 * d->pad - d->k) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - d->k) / d->stride + 1)
             return nsg_fail(NSG_E_INVALID, "%s: output extent does not match Conv2d geometry", fn);
         if (d->C_in == 1) {
-            if (!(d->k == 4 && d->stride == 2 && d->pad == 1 && d->C_out % cm == 0))
-                return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in=1 needs k=4,stride=2,pad=1 and C_out%%%d==0", fn, cm);
+            if (!(d->k == 4 && d->stride == 2 && d->pad == 1 && d->C_out % cm == 0 && nsg_c1_stencil_supported(d->C_out)))
+                return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in=1 needs k=4,stride=2,pad=1, C_out%%%d==0 and C_out<=1024", fn, cm);
             return K_CONV_C1;
         }
         if (d->C_in % cm || d->C_out % cm) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of %d", fn, cm);
@@ -222,7 +227,8 @@ int classify(const nsg_conv_desc *d, const char *fn)
     if (!(d->k == 4 && d->stride == 2 && d->pad == 1)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: ConvTranspose2d needs k=4,stride=2,pad=1", fn);
     if (d->OH != 2 * d->IH || d->OW != 2 * d->IW) return nsg_fail(NSG_E_INVALID, "%s: output extent does not match ConvTranspose2d geometry", fn);
     if (d->C_out == 1) {
-        if (d->C_in % cm) return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in must be a multiple of %d", fn, cm);
+        if (d->C_in % cm || !nsg_c1_stencil_supported(d->C_in))
+            return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in must be a multiple of %d and <= 1024", fn, cm);
         return K_CONVT_C1;
     }
     if (d->C_in % cm || d->C_out % cm) return nsg_fail(NSG_E_UNSUPPORTED, "%s: channels must be multiples of %d", fn, cm);
@@ -259,15 +265,6 @@ GatherGemmParams gg_1x1(const void *in, const void *w, const float *bias, void *
     return p;
 }
 
-void launch_im2col(const nsg_conv_desc *d, const float *img, void *patches, int LH, int LW, int HH, int WW, hipStream_t s)
-{
-    const int64_t n = (int64_t)d->B * LH * LW * 4;
-    if (d->dtype == NSG_BF16)
-        hipLaunchKernelGGL((im2col_c1_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, s, img, reinterpret_cast<bf16_t *>(patches), d->B, LH, LW, HH, WW);
-    else
-        hipLaunchKernelGGL((im2col_c1_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, s, img, reinterpret_cast<float *>(patches), d->B, LH, LW, HH, WW);
-}
-
 }  // namespace
 
 extern "C" {
@@ -275,41 +272,71 @@ extern "C" {
 size_t nsg_packed_weight_floats(const nsg_conv_desc *d)
 {
     if (!d) return 0;
-    return (size_t)d->k * d->k * d->C_in * d->C_out;
+    const size_t n = (size_t)d->k * d->k * d->C_in * d->C_out;
+    // the single-channel layers keep one image as fp32 [C][16] for the stencil kernels whatever d->dtype is
+    const bool c1 = (!d->transposed && d->C_in == 1) || (d->transposed && d->C_out == 1);
+    return (c1 && d->dtype == NSG_BF16) ? 2 * n : n;
 }
 
 int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, void *w_fwd, void *w_dgrad, void *stream)
 {
-    const int kind = classify(d, "nsg_pack_conv_weights");
-    if (kind < 0) return kind;
-    NSG_REQUIRE(w, NSG_E_INVALID, "nsg_pack_conv_weights: null weights");
+    return nsg_pack_conv_weights_batch(1, d, &w, &w_fwd, &w_dgrad, stream);
+}
+
+int nsg_pack_conv_weights_batch(int32_t n, const nsg_conv_desc *descs, const float *const *w, void *const *w_fwd,
+                                void *const *w_dgrad, void *stream)
+{
+    NSG_REQUIRE(n >= 0 && (n == 0 || (descs && w && w_fwd && w_dgrad)), NSG_E_INVALID, "nsg_pack_conv_weights_batch: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const int T = d->k * d->k, CI = d->C_in, CO = d->C_out;
-    const int nb = ew_blocks((int64_t)T * CI * CO);
-    const bool bf = d->dtype == NSG_BF16;
-    auto pack = [&](void *dst, int TT, int NN, int CC, int sn, int sc, int flip) {
-        if (bf) hipLaunchKernelGGL((pack_w_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, w, reinterpret_cast<bf16_t *>(dst), TT, NN, CC, sn, sc, flip);
-        else    hipLaunchKernelGGL((pack_w_kernel<float>), dim3(nb), dim3(256), 0, s, w, reinterpret_cast<float *>(dst), TT, NN, CC, sn, sc, flip);
+    PackJobs jobs;
+    int nj = 0;
+    int64_t biggest = 0;
+    auto flush = [&]() -> int {
+        if (nj == 0) return NSG_OK;
+        int64_t nb = nsg_cdiv(biggest, 256);
+        if (nb > 256) nb = 256;
+        hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)nb, (unsigned)nj), dim3(256), 0, s, jobs);
+        nj = 0;
+        biggest = 0;
+        return nsg_check_launch("pack_w_kernel");
     };
-    switch (kind) {
-    case K_CONV:  // w[co][ci][t]
-        if (w_fwd) pack(w_fwd, T, CO, CI, CI * T, T, 0);
-        if (w_dgrad) pack(w_dgrad, T, CI, CO, T, CI * T, d->stride == 1 ? 1 : 0);
-        break;
-    case K_CONVT:  // w[ci][co][t]
-        if (w_fwd) pack(w_fwd, T, CO, CI, T, CO * T, 0);
-        if (w_dgrad) pack(w_dgrad, T, CI, CO, CO * T, T, 0);
-        break;
-    case K_CONV_C1:  // w[co][t] : forward is a 1x1 GEMM over the 16 patch taps
-        if (w_fwd) pack(w_fwd, 1, CO, 16, 16, 1, 0);    // [n=co][c=t]
-        if (w_dgrad) pack(w_dgrad, 1, 16, CO, 1, 16, 0);  // [n=t][c=co]
-        break;
-    case K_CONVT_C1:  // w[ci][t]
-        if (w_fwd) pack(w_fwd, 1, 16, CI, 1, 16, 0);     // [n=t][c=ci]
-        if (w_dgrad) pack(w_dgrad, 1, CI, 16, 16, 1, 0);  // [n=ci][c=t]
-        break;
+    int rc = NSG_OK;
+    auto add = [&](const float *src, void *dst, int T, int NN, int CC, int sn, int sc, int flip, int bf) {
+        if (!dst || rc) return;
+        if (nj == PACK_MAX_JOBS) rc = flush();
+        PackJob &j = jobs.job[nj++];
+        j.src = src; j.dst = dst; j.T = T; j.NN = NN; j.CC = CC; j.sn = sn; j.sc = sc; j.flip = flip; j.bf16 = bf;
+        const int64_t total = (int64_t)T * NN * CC;
+        if (total > biggest) biggest = total;
+    };
+    for (int i = 0; i < n; ++i) {
+        const nsg_conv_desc *d = descs + i;
+        const int kind = classify(d, "nsg_pack_conv_weights");
+        if (kind < 0) return kind;
+        NSG_REQUIRE(w[i], NSG_E_INVALID, "nsg_pack_conv_weights: null weights");
+        const int T = d->k * d->k, CI = d->C_in, CO = d->C_out;
+        const int bf = d->dtype == NSG_BF16 ? 1 : 0;
+        switch (kind) {
+        case K_CONV:  // w[co][ci][t]
+            add(w[i], w_fwd[i], T, CO, CI, CI * T, T, 0, bf);
+            add(w[i], w_dgrad[i], T, CI, CO, T, CI * T, d->stride == 1 ? 1 : 0, bf);
+            break;
+        case K_CONVT:  // w[ci][co][t]
+            add(w[i], w_fwd[i], T, CO, CI, T, CO * T, 0, bf);
+            add(w[i], w_dgrad[i], T, CI, CO, CO * T, T, 0, bf);
+            break;
+        case K_CONV_C1:  // w[co][t] : forward is the stencil kernel (fp32 [co][16] = the parameter's own layout)
+            add(w[i], w_fwd[i], 1, CO, 16, 16, 1, 0, 0);
+            add(w[i], w_dgrad[i], 1, 16, CO, 1, 16, 0, bf);   // [n=t][c=co]
+            break;
+        case K_CONVT_C1:  // w[ci][t] : the data gradient is the stencil kernel (fp32 [ci][16])
+            add(w[i], w_fwd[i], 1, 16, CI, 1, 16, 0, bf);     // [n=t][c=ci]
+            add(w[i], w_dgrad[i], 1, CI, 16, 16, 1, 0, 0);
+            break;
+        }
+        if (rc) return rc;
     }
-    return nsg_check_launch("pack_w_kernel");
+    return flush();
 }
 
 size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d)
@@ -323,8 +350,12 @@ size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d)
     int A, C, taps;
     if (kind == K_CONV) { A = d->C_out; C = d->C_in; taps = T; }
     else if (kind == K_CONVT) { A = d->C_in; C = d->C_out; taps = T; }
-    else if (kind == K_CONV_C1) { A = d->C_out; C = 16; taps = 1; bytes += patches_bytes(d); }
-    else { A = d->C_in; C = 16; taps = 1; bytes += patches_bytes(d); }
+    else {   // single-channel layers: the dots / patches staging image of the GEMM-side passes, or the stencil wgrad's partials
+        const size_t sb = nsg_c1_stencil_wgrad_workspace_bytes(kind == K_CONV_C1 ? d->C_out : d->C_in);
+        bytes += patches_bytes(d) > sb ? patches_bytes(d) : sb;
+        bytes += colsum_ws_bytes((int64_t)d->B * d->OH * d->OW, d->C_out);
+        return bytes;
+    }
     bytes += nsg_align_up(nsg_wgrad_workspace_bytes(Mp, taps, A, C), 256);
     bytes += colsum_ws_bytes((int64_t)d->B * d->OH * d->OW, d->C_out);
     bytes += stats_tiles_bytes(d);
@@ -358,14 +389,12 @@ static int conv_forward_impl(const nsg_conv_desc *d, const void *x, const void *
     NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward: workspace too small");
     const int64_t Mp = lowres_pixels(d);
     if (kind == K_CONV_C1) {   // x is the fp32 single-channel image
-        NSG_REQUIRE(!(flags & NSG_RELU_IN), NSG_E_UNSUPPORTED, "nsg_conv_forward: NSG_RELU_IN on a single-channel input");
-        launch_im2col(d, reinterpret_cast<const float *>(x), workspace, d->OH, d->OW, d->IH, d->IW, s);
-        int rc = nsg_check_launch("im2col_c1_kernel");
-        if (rc) return rc;
-        GatherGemmParams p1 = gg_1x1(workspace, w_fwd, bias, y, Mp, 16, d->C_out, flags & NSG_TANH_OUT, d->dtype, out_dtype);
-        p1.stats = stats;
-        if (stats_tiles) *stats_tiles = nsg_gather_gemm_row_tiles(p1);
-        return nsg_launch_gather_gemm(p1, s);
+        NSG_REQUIRE(!(flags & (NSG_RELU_IN | NSG_TANH_OUT | NSG_RELU_OUT)), NSG_E_UNSUPPORTED,
+                    "nsg_conv_forward: no fused activations on the single-input-channel layer");
+        NSG_REQUIRE(stats == nullptr, NSG_E_INVALID, "nsg_conv_forward: internal: tile statistics on the stencil path");
+        NSG_REQUIRE(nsg_aligned16(w_fwd) && nsg_aligned16(y), NSG_E_INVALID, "nsg_conv_forward: operands must be 16-byte aligned");
+        return nsg_launch_c1_stencil_fwd(reinterpret_cast<const float *>(x), reinterpret_cast<const float *>(w_fwd), bias, y, out_dtype,
+                                         d->B, d->OH, d->OW, d->IH, d->IW, d->C_out, s);
     }
     NSG_REQUIRE(stats == nullptr, NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: not available for a single-channel output");
     // K_CONVT_C1: per-input-pixel tap products (fp32), then the 4-tap gather with bias (+tanh) into the fp32 image y
@@ -390,6 +419,13 @@ int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, const void *
     NSG_REQUIRE(d && mean && invstd, NSG_E_INVALID, "nsg_conv_forward_bnstats: null pointer");
     NSG_REQUIRE(!(flags & (NSG_TANH_OUT | NSG_RELU_OUT)), NSG_E_UNSUPPORTED, "nsg_conv_forward_bnstats: statistics are of the linear output");
     NSG_REQUIRE(workspace && workspace_bytes >= nsg_conv_workspace_bytes(d), NSG_E_WORKSPACE, "nsg_conv_forward_bnstats: workspace too small");
+    if (!d->transposed && d->C_in == 1) {   // stencil layer: the statistics are a separate pass over y
+        int rc = conv_forward_impl(d, x, w_fwd, bias, y, flags, workspace, workspace_bytes, stream, nullptr, nullptr);
+        if (rc) return rc;
+        const int ydt = (flags & NSG_OUT_F32) ? NSG_F32 : d->dtype;
+        return nsg_bn_stats(y, (int64_t)d->B * d->OH * d->OW, d->C_out, ydt, eps, momentum, mean, invstd, running_mean, running_var,
+                            workspace, workspace_bytes, stream);
+    }
     // the tile statistics live at the END of the workspace (the C=1 staging image uses its start)
     const size_t tb = stats_tiles_bytes(d);
     float *tiles = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + nsg_conv_workspace_bytes(d) - tb);
@@ -434,10 +470,9 @@ int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, 
     const int64_t Mp = lowres_pixels(d);
     if (kind == K_CONVT_C1) {
         // dy is the fp32 image: dx[pix][ci] = sum_t patch(dy)[pix][t] * w[ci][t]
-        launch_im2col(d, reinterpret_cast<const float *>(dy), workspace, d->IH, d->IW, d->OH, d->OW, s);
-        int rc = nsg_check_launch("im2col_c1_kernel");
-        if (rc) return rc;
-        return nsg_launch_gather_gemm(gg_1x1(workspace, w_dgrad, nullptr, dx, Mp, 16, d->C_in, 0, d->dtype, d->dtype), s);
+        NSG_REQUIRE(nsg_aligned16(w_dgrad) && nsg_aligned16(dx), NSG_E_INVALID, "nsg_conv_dgrad: operands must be 16-byte aligned");
+        return nsg_launch_c1_stencil_fwd(reinterpret_cast<const float *>(dy), reinterpret_cast<const float *>(w_dgrad), nullptr, dx,
+                                         d->dtype, d->B, d->IH, d->IW, d->OH, d->OW, d->C_in, s);
     }
     // K_CONV_C1: dots[pix][t] = sum_co dy[pix][co] * w[co][t] (fp32), scattered back onto the fp32 image dx
     float *dots = reinterpret_cast<float *>(workspace);
@@ -459,43 +494,40 @@ int nsg_conv_wgrad(const nsg_conv_desc *d, const void *x, const void *dy, float 
     char *ws = reinterpret_cast<char *>(workspace);
     const int64_t Mp = lowres_pixels(d);
     const int relu_x = (flags & NSG_RELU_IN) ? 1 : 0;
+    if (kind == K_CONV_C1 || kind == K_CONVT_C1) {
+        const size_t sb = nsg_c1_stencil_wgrad_workspace_bytes(kind == K_CONV_C1 ? d->C_out : d->C_in);
+        NSG_REQUIRE(workspace_bytes >= sb + colsum_ws_bytes((int64_t)d->B * d->OH * d->OW, d->C_out), NSG_E_WORKSPACE,
+                    "nsg_conv_wgrad: workspace too small");
+        if (kind == K_CONV_C1) {   // x is the fp32 image, dy the C_out-channel tensor; dbias = its column sums
+            NSG_REQUIRE(!relu_x, NSG_E_UNSUPPORTED, "nsg_conv_wgrad: NSG_RELU_IN on a single-channel input");
+            NSG_REQUIRE(nsg_aligned16(dy), NSG_E_INVALID, "nsg_conv_wgrad: dy must be 16-byte aligned");
+            return nsg_launch_c1_stencil_wgrad(reinterpret_cast<const float *>(x), dy, d->dtype, 0, dw, dbias, d->B, d->OH, d->OW, d->IH,
+                                               d->IW, d->C_out, ws, sb, s);
+        }
+        // K_CONVT_C1: dy is the fp32 image, x the C_in-channel tensor; dbias = sum of the image
+        NSG_REQUIRE(nsg_aligned16(x), NSG_E_INVALID, "nsg_conv_wgrad: x must be 16-byte aligned");
+        int rc = nsg_launch_c1_stencil_wgrad(reinterpret_cast<const float *>(dy), x, d->dtype, relu_x, dw, nullptr, d->B, d->IH, d->IW,
+                                             d->OH, d->OW, d->C_in, ws, sb, s);
+        if (rc) return rc;
+        if (dbias) return colsum(dy, NSG_F32, (int64_t)d->B * d->OH * d->OW, 1, dbias, ws + sb, s);
+        return NSG_OK;
+    }
     WgradParams p = {};
     p.dtype = d->dtype;
     p.B = d->B; p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
     p.Mp = (int)Mp;
-    void *stage = nullptr;
-    if (kind == K_CONV_C1 || kind == K_CONVT_C1) {
-        stage = ws;
-        ws += patches_bytes(d);
-        p.B = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
-        p.PH = 1; p.PW = (int)Mp; p.QH = 1; p.QW = (int)Mp; p.C = 16;
-    }
-    int dy_dtype = d->dtype;   // storage type of dy for the bias gradient
-    switch (kind) {
-    case K_CONV:
+    if (kind == K_CONV) {
         p.P = dy; p.PH = d->OH; p.PW = d->OW; p.A = d->C_out;
         p.Q = x; p.QH = d->IH; p.QW = d->IW; p.C = d->C_in; p.relu_q = relu_x;
-        break;
-    case K_CONVT:
+    } else {   // K_CONVT
         p.P = x; p.PH = d->IH; p.PW = d->IW; p.A = d->C_in; p.relu_p = relu_x;
         p.Q = dy; p.QH = d->OH; p.QW = d->OW; p.C = d->C_out;
-        break;
-    case K_CONV_C1:   // x is the fp32 image
-        NSG_REQUIRE(!relu_x, NSG_E_UNSUPPORTED, "nsg_conv_wgrad: NSG_RELU_IN on a single-channel input");
-        launch_im2col(d, reinterpret_cast<const float *>(x), stage, d->OH, d->OW, d->IH, d->IW, s);
-        p.P = dy; p.A = d->C_out; p.Q = stage;
-        break;
-    case K_CONVT_C1:  // dy is the fp32 image
-        launch_im2col(d, reinterpret_cast<const float *>(dy), stage, d->IH, d->IW, d->OH, d->OW, s);
-        p.P = x; p.A = d->C_in; p.relu_p = relu_x; p.Q = stage;
-        dy_dtype = NSG_F32;
-        break;
     }
     const size_t wg_bytes = nsg_align_up(nsg_wgrad_workspace_bytes(Mp, p.KH * p.KW, p.A, p.C), 256);
     int rc = nsg_launch_wgrad(p, dw, ws, wg_bytes, s);
     if (rc) return rc;
     ws += wg_bytes;
-    if (dbias) return colsum(dy, dy_dtype, (int64_t)d->B * d->OH * d->OW, d->C_out, dbias, ws, s);
+    if (dbias) return colsum(dy, d->dtype, (int64_t)d->B * d->OH * d->OW, d->C_out, dbias, ws, s);
     return NSG_OK;
 }
 

@@ -258,32 +258,40 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
     constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
     const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);
-    constexpr int NV = BN / EPO;
-    for (int f = tid; f < BM * NV; f += 256) {
-        const int row = f / NV;
-        const int cq = (f - row * NV) * EPO;
-        const int off = rowoff[row];
-        const int col = n0 + cq;
-        if (off < 0 || col >= p.CO) continue;
-        float v[EPO];
+    constexpr int NV = BN / EPO;     // 16-byte pieces per tile row; divides 256, so a thread keeps its columns
+    static_assert(256 % NV == 0, "a thread's column group must not change from row to row");
+    const int cq = (tid % NV) * EPO;
+    const int col = n0 + cq;
+    float bv[EPO];
 #pragma unroll
-        for (int e = 0; e < EPO; e += 4) {
-            const v4f t = *reinterpret_cast<const v4f *>(Cs + row * CP + cq + e);
-            v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
-        }
+    for (int e = 0; e < EPO; ++e) bv[e] = (p.bias && col + e < p.CO) ? p.bias[col + e] : 0.f;
+    const bool full_vec = vec_store && col + EPO - 1 < p.CO;
+    if (col < p.CO) {
+        for (int row = tid / NV; row < BM; row += 256 / NV) {
+            const int off = rowoff[row];
+            if (off < 0) continue;
+            float v[EPO];
 #pragma unroll
-        for (int e = 0; e < EPO; ++e) {
-            if (p.bias && col + e < p.CO) v[e] += p.bias[col + e];
-            if (tanh_out) v[e] = tanhf(v[e]);
-            if (relu_out) v[e] = fmaxf(v[e], 0.f);
-        }
-        TO *dst = gout + (size_t)off + col;
-        if (vec_store && col + EPO - 1 < p.CO) {
-            Elem<TO>::store16(dst, v);
-        } else {
+            for (int e = 0; e < EPO; e += 4) {
+                const v4f t = *reinterpret_cast<const v4f *>(Cs + row * CP + cq + e);
+                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+            }
 #pragma unroll
-            for (int e = 0; e < EPO; ++e)
-                if (col + e < p.CO) Elem<TO>::put(dst + e, v[e]);
+            for (int e = 0; e < EPO; ++e) v[e] += bv[e];
+            if (tanh_out) {
+#pragma unroll
+                for (int e = 0; e < EPO; ++e) v[e] = tanhf(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < EPO; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];   // (a select keeps NaNs visible)
+            TO *dst = gout + (size_t)off + col;
+            if (full_vec) {
+                Elem<TO>::store16(dst, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPO; ++e)
+                    if (col + e < p.CO) Elem<TO>::put(dst + e, v[e]);
+            }
         }
     }
 

@@ -70,14 +70,42 @@ import os as _os
 FUSED_BN_STATS = _os.environ.get("NSG_FUSED_BN_STATS", "0") == "1"
 
 
+# num_batches_tracked += 1 per BatchNorm is ten tiny launches a step; a fused step collects the counters here
+# and bumps them with one torch._foreach_add_ (deferred_batch_counters)
+_nbt_pending = None
+
+
+class deferred_batch_counters:
+    def __enter__(self):
+        global _nbt_pending
+        self._outer = _nbt_pending
+        _nbt_pending = []
+        return self
+
+    def __exit__(self, *exc):
+        global _nbt_pending
+        pending, _nbt_pending = _nbt_pending, self._outer
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def _bump(bn: "BNParams"):
+    if bn.num_batches_tracked is None:
+        return
+    if _nbt_pending is not None:
+        _nbt_pending.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
 def _conv_bn(d, x, wf, conv: ConvParams, bn: BNParams, training: bool, flags=0):
     """conv (+fused input ReLU) followed by BatchNorm statistics: one fused call in training mode
     (the statistics come out of the conv epilogue), two calls in eval mode."""
     if training and FUSED_BN_STATS:
         h, mean, invstd = ops.conv_forward_bnstats(d, x, wf, conv.bias, flags=flags, running_mean=bn.running_mean,
                                                    running_var=bn.running_var)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        _bump(bn)
         return h, mean, invstd
     h = ops.conv_forward(d, x, wf, conv.bias, flags=flags)
     mean, invstd = _bn_forward(h, bn, training)
@@ -88,8 +116,7 @@ def _bn_forward(h, bn: BNParams, training: bool):
     C = bn.weight.numel()
     if training:
         mean, invstd = ops.bn_stats(h, C, bn.running_mean, bn.running_var)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        _bump(bn)
     else:
         mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var)
     return mean, invstd
@@ -98,18 +125,18 @@ def _bn_forward(h, bn: BNParams, training: bool):
 # ------------------------------------------------------------------------------------------------
 # ResBlock   y = relu(x) + BN(conv1x1(relu(BN(conv3x3(relu(x))))))      (src/models.py:145-158)
 # ------------------------------------------------------------------------------------------------
-def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_out=False):
+def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_out=False, packs=None):
     """r = relu(x) NHWC of the compute dtype, ALREADY ReLU'd by its producer: the reference's block starts
     with an in-place ReLU that overwrites its input (models.py:149), so nothing ever needs the un-ReLU'd
     tensor and the backward mask (x > 0) equals (r > 0).  Applying that ReLU where the tensor is written
     removes all ReLU work from the GEMM operand staging.
     out_dtype: storage type of the output (default: r's) -- the encoder's last block writes fp32 for the
-    quantiser.  relu_out: store relu(y) because the consumer is again a ResBlock / the decoder's ReLU."""
+    quantiser.  relu_out: store relu(y) because the consumer is again a ResBlock / the decoder's ReLU.
+    packs: ((w_fwd, w_dgrad) of conv1, of conv2) when the caller packed the weights already (pack_all)."""
     B, H, W, D = r.shape
     d1 = ops.conv_desc(B, H, W, D, D, 3, 1, 1, dtype=r.dtype)
     d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0, dtype=r.dtype)
-    wf1, wd1 = ops.pack_weights(d1, P.conv1.weight)
-    wf2, wd2 = ops.pack_weights(d2, P.conv2.weight)
+    (wf1, wd1), (wf2, wd2) = packs if packs is not None else (ops.pack_weights(d1, P.conv1.weight), ops.pack_weights(d2, P.conv2.weight))
     h1, m1, i1 = _conv_bn(d1, r, wf1, P.conv1, P.bn1, training)
     a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
     h2, m2, i2 = _conv_bn(d2, a1, wf2, P.conv2, P.bn2, training)
@@ -132,7 +159,8 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     dh2, dg2, db2n = ops.bn_backward(h2, None, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7], dx_colsum=dbias2)
     dw2, _ = ops.conv_wgrad(d2, a1, dh2, P.conv2.weight.shape, dw=o[4], want_bias=False)
     da1 = ops.conv_dgrad(d2, dh2, wd2)
-    dh1, dg1, db1n = ops.bn_backward(h1, a1, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3], dx_colsum=dbias1)
+    dh1, dg1, db1n = ops.bn_backward(h1, None, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3], dx_colsum=dbias1,
+                                     relu_beta=P.bn1.bias)   # ReLU mask re-derived from h1: a1 is not read
     dw1, _ = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, dw=o[0], want_bias=False)   # x is the stored relu(x)
     dx = None
     if need_dx:
@@ -144,20 +172,21 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
 # ------------------------------------------------------------------------------------------------
 # Encoder   (src/models.py:164-171)
 # ------------------------------------------------------------------------------------------------
-def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32):
+def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32, packs=None):
     """x fp32 NHWC (B, H, W, 1) -> z_e fp32 NHWC (B, H/4, W/4, D).  dtype: storage type of the activations in
     between (fp32 = parity mode, bf16 = throughput mode); the quantiser input z_e is fp32 in both."""
     B, H, W, _ = x.shape
     D = P.conv0.weight.shape[0]
     d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1, dtype=dtype)
-    wf0, _ = ops.pack_weights(d0, P.conv0.weight, want_dgrad=False)
+    pk = packs if packs is not None else {}
+    wf0, _ = pk["conv0"] if packs is not None else ops.pack_weights(d0, P.conv0.weight, want_dgrad=False)
     h0, m0, i0 = _conv_bn(d0, x, wf0, P.conv0, P.bn0, training)
     a0 = ops.bn_apply(h0, m0, i0, P.bn0.weight, P.bn0.bias, relu=True)
     d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1, dtype=dtype)
-    wf3, wd3 = ops.pack_weights(d3, P.conv3.weight)
+    wf3, wd3 = pk["conv3"] if packs is not None else ops.pack_weights(d3, P.conv3.weight)
     e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias, flags=NSG_RELU_OUT)     # stored ReLU'd: its only consumer is a ResBlock
-    r4, s4 = resblock_forward(e3, P.res4, training, relu_out=True)
-    ze, s5 = resblock_forward(r4, P.res5, training, out_dtype=torch.float32)
+    r4, s4 = resblock_forward(e3, P.res4, training, relu_out=True, packs=pk.get("res4"))
+    ze, s5 = resblock_forward(r4, P.res5, training, out_dtype=torch.float32, packs=pk.get("res5"))
     saved = (x, h0, a0, m0, i0, d0, d3, wd3, s4, s5)
     return ze, saved
 
@@ -173,7 +202,7 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
     dw3, db3 = ops.conv_wgrad(d3, a0, de3, P.conv3.weight.shape, dw=o[4], dbias=o[5])
     da0 = ops.conv_dgrad(d3, de3, wd3)
     db0 = o[1] if o[1] is not None else torch.empty(h0.shape[-1], dtype=torch.float32, device=h0.device)
-    dh0, dg0, dbe0 = ops.bn_backward(h0, a0, da0, m0, i0, P.bn0.weight, dgamma=o[2], dbeta=o[3], dx_colsum=db0)
+    dh0, dg0, dbe0 = ops.bn_backward(h0, None, da0, m0, i0, P.bn0.weight, dgamma=o[2], dbeta=o[3], dx_colsum=db0, relu_beta=P.bn0.bias)
     dw0, _ = ops.conv_wgrad(d0, x, dh0, P.conv0.weight.shape, dw=o[0], want_bias=False)
     return [dw0, db0, dg0, dbe0, dw3, db3] + g4 + g5
 
@@ -181,18 +210,19 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
 # ------------------------------------------------------------------------------------------------
 # Decoder   (src/models.py:175-184)
 # ------------------------------------------------------------------------------------------------
-def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32):
+def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None):
     """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype."""
     B, H, W, D = zq.shape
     zq = ops.convert(zq, dtype, relu=True)                       # decoder.0's leading ReLU, applied once here
-    r0, s0 = resblock_forward(zq, P.res0, training, relu_out=True)
-    r1, s1 = resblock_forward(r0, P.res1, training, relu_out=True)   # decoder.2 ReLU applied at the producer
+    pk = packs if packs is not None else {}
+    r0, s0 = resblock_forward(zq, P.res0, training, relu_out=True, packs=pk.get("res0"))
+    r1, s1 = resblock_forward(r0, P.res1, training, relu_out=True, packs=pk.get("res1"))   # decoder.2 ReLU applied at the producer
     dT = ops.conv_desc(B, H, W, D, D, 4, 2, 1, transposed=True, dtype=dtype)
-    wfT, wdT = ops.pack_weights(dT, P.convt3.weight)
+    wfT, wdT = pk["convt3"] if packs is not None else ops.pack_weights(dT, P.convt3.weight)
     u, m, i = _conv_bn(dT, r1, wfT, P.convt3, P.bn4, training)
     a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
     d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True, dtype=dtype)
-    wf6, wd6 = ops.pack_weights(d6, P.convt6.weight)
+    wf6, wd6 = pk["convt6"] if packs is not None else ops.pack_weights(d6, P.convt6.weight)
     xt = ops.conv_forward(d6, a, wf6, P.convt6.bias, flags=NSG_TANH_OUT)  # decoder.7 Tanh fused into the epilogue
     saved = (r1, u, a, m, i, xt, dT, d6, wdT, wd6, s0, s1)
     return xt, saved
@@ -207,13 +237,34 @@ def decoder_backward(dxt, saved, P: DecoderParams, need_dz: bool = True, dxt_is_
     dw6, db6 = ops.conv_wgrad(d6, a, dpre, P.convt6.weight.shape, dw=o[20], dbias=o[21])
     da = ops.conv_dgrad(d6, dpre, wd6)
     dbT = o[17] if o[17] is not None else torch.empty(u.shape[-1], dtype=torch.float32, device=u.device)
-    du, dg4, dbe4 = ops.bn_backward(u, a, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19], dx_colsum=dbT)
+    du, dg4, dbe4 = ops.bn_backward(u, None, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19], dx_colsum=dbT, relu_beta=P.bn4.bias)
     dwT, _ = ops.conv_wgrad(dT, r1, du, P.convt3.weight.shape, dw=o[16], want_bias=False)   # r1 is stored ReLU'd
     dr1_pre = ops.conv_dgrad(dT, du, wdT)
     dr1 = ops.relu_backward_add(dr1_pre, None, r1)
     dr0, g1 = resblock_backward(dr1, s1, P.res1, gout=o[8:16] if gout is not None else None)
     dzq, g0 = resblock_backward(dr0, s0, P.res0, need_dx=need_dz, gout=o[0:8] if gout is not None else None)
     return dzq, g0 + g1 + [dwT, dbT, dg4, dbe4, dw6, db6]
+
+
+def pack_all(encP: EncoderParams, decP: DecoderParams, B: int, H: int, W: int, dtype):
+    """Every packed weight image of one training step in ONE launch (nsg_pack_conv_weights_batch).
+    (B, H, W): the mel image extent.  Returns (encoder packs, decoder packs) for encoder_forward / decoder_forward."""
+    D = encP.conv0.weight.shape[0]
+    d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1, dtype=dtype)
+    d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1, dtype=dtype)
+    h, w = d3.OH, d3.OW
+    r3 = ops.conv_desc(B, h, w, D, D, 3, 1, 1, dtype=dtype)
+    r1 = ops.conv_desc(B, h, w, D, D, 1, 1, 0, dtype=dtype)
+    dT = ops.conv_desc(B, h, w, D, D, 4, 2, 1, transposed=True, dtype=dtype)
+    d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True, dtype=dtype)
+    jobs = [(d0, encP.conv0.weight, True, False), (d3, encP.conv3.weight, True, True)]
+    for rb in (encP.res4, encP.res5, decP.res0, decP.res1):
+        jobs += [(r3, rb.conv1.weight, True, True), (r1, rb.conv2.weight, True, True)]
+    jobs += [(dT, decP.convt3.weight, True, True), (d6, decP.convt6.weight, True, True)]
+    pk = ops.pack_weights_batch(jobs)
+    enc = {"conv0": pk[0], "conv3": pk[1], "res4": (pk[2], pk[3]), "res5": (pk[4], pk[5])}
+    dec = {"res0": (pk[6], pk[7]), "res1": (pk[8], pk[9]), "convt3": pk[10], "convt6": pk[11]}
+    return enc, dec
 
 
 # ------------------------------------------------------------------------------------------------

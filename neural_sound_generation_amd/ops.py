@@ -198,6 +198,30 @@ def pack_weights(d: ConvDesc, w, want_fwd=True, want_dgrad=True):
     return wf, wd
 
 
+def pack_weights_batch(jobs):
+    """jobs: list of (desc, weight, want_fwd, want_dgrad) -> list of (w_fwd, w_dgrad); ONE kernel launch for all of them
+    (a training step re-packs every layer's weights after each optimiser step)."""
+    n = len(jobs)
+    if n == 0:
+        return []
+    descs = (ConvDesc * n)()
+    wp, fp, dp = (c_void_p * n)(), (c_void_p * n)(), (c_void_p * n)()
+    out = []
+    for i, (d, w, want_fwd, want_dgrad) in enumerate(jobs):
+        _chk(w, "weight")
+        ne = _lib.query("nsg_packed_weight_floats", byref(d))
+        wf = torch.empty(ne, dtype=torch_dtype(d.dtype), device=w.device) if want_fwd else None
+        wd = torch.empty(ne, dtype=torch_dtype(d.dtype), device=w.device) if want_dgrad else None
+        ctypes.memmove(ctypes.addressof(descs[i]), ctypes.addressof(d), ctypes.sizeof(ConvDesc))
+        wp[i] = w.data_ptr()
+        fp[i] = wf.data_ptr() if wf is not None else None
+        dp[i] = wd.data_ptr() if wd is not None else None
+        out.append((wf, wd))
+    _lib.call("nsg_pack_conv_weights_batch", c_int32(n), ctypes.cast(descs, c_void_p), ctypes.cast(wp, c_void_p),
+              ctypes.cast(fp, c_void_p), ctypes.cast(dp, c_void_p), _stream())
+    return out
+
+
 def _conv_ws(d, device):
     nb = _lib.query("nsg_conv_workspace_bytes", byref(d))
     return WS.get(nb, device), nb
@@ -302,8 +326,10 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_resid
     return y
 
 
-def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out=None, dx_colsum=None):
-    """dx_colsum: optional [C] tensor receiving the column sums of dx (= bias gradient of the conv in front)."""
+def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out=None, dx_colsum=None, relu_beta=None):
+    """dx_colsum: optional [C] tensor receiving the column sums of dx (= bias gradient of the conv in front).
+    ReLU mask of a fused BatchNorm+ReLU forward: relu_beta (the forward's beta: mask re-derived from x) or
+    y_relu (the stored forward output)."""
     _chk(x, "x", None); _chk(dy, "dy", x.dtype)
     if y_relu is not None:
         _chk(y_relu, "y_relu", x.dtype)
@@ -316,7 +342,7 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
-    _lib.call("nsg_bn_backward", _p(x), _p(y_relu), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+    _lib.call("nsg_bn_backward", _p(x), _p(y_relu), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(relu_beta), _p(dx), _p(dgamma), _p(dbeta),
               _p(dx_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return dx, dgamma, dbeta
 

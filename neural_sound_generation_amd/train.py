@@ -53,7 +53,12 @@ class FusedTrainStep:
             raise RuntimeError("FusedTrainStep needs model.train()")
         x = Fn.to_nhwc(c)
         B, H, T, _ = x.shape
-        ze, es = engine.encoder_forward(x, self.encP, True, dtype=self.dtype)
+        with engine.deferred_batch_counters():
+            return self._forward_backward(x, g, B, H, T)
+
+    def _forward_backward(self, x, g, B, H, T):
+        enc_packs, dec_packs = engine.pack_all(self.encP, self.decP, B, H, T, self.dtype)
+        ze, es = engine.encoder_forward(x, self.encP, True, dtype=self.dtype, packs=enc_packs)
         D = ze.shape[-1]
         K = self.codebook.shape[0]
         idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True)
@@ -62,7 +67,7 @@ class FusedTrainStep:
         if self.spk is not None and g is not None:
             g = g.view(-1).to(torch.int64).contiguous()
             zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g), out_dtype=self.dtype)
-        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype)
+        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
         loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
         dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)

@@ -291,23 +291,23 @@ def test_conv_bf16_mode(case):
     wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
     w = torch.randn(*wshape, generator=g) * 0.1
     b = torch.randn(Co, generator=g) * 0.1
-    wq = rnd(w)                                     # what the packed bf16 image holds
+    # what the packed images hold: bf16, except that the stencil kernels of the single-channel layers (the forward
+    # of a C_in=1 conv, the data gradient of a C_out=1 transposed conv) read the fp32 weights and the fp32 image
+    wq = rnd(w) if Ci > 1 else w
     xr = x.clone().requires_grad_(True)
     wr = wq.clone().requires_grad_(True)
     br = b.clone().requires_grad_(True)
     xin = F.relu(xr) if relu_in else xr
-    if Ci == 1:
-        xin_eff = rnd(xin)                           # the im2col image of the fp32 input is stored in bf16
-    else:
-        xin_eff = xin
-    y = F.conv_transpose2d(xin_eff, wr, br, stride=s, padding=p) if tr else F.conv2d(xin_eff, wr, br, stride=s, padding=p)
+    y = F.conv_transpose2d(xin, wr, br, stride=s, padding=p) if tr else F.conv2d(xin, wr, br, stride=s, padding=p)
     dy = torch.randn(y.shape, generator=g)
     dyq = rnd(dy) if Co > 1 else dy
-    gx, gw, gb = torch.autograd.grad(y, [xin_eff if Ci > 1 else xr, wr, br], dyq)
+    gx, gw, gb = torch.autograd.grad(y, [xin if Ci > 1 else xr, wr, br], dyq)
+    if Co == 1:   # data gradient with the unrounded weights
+        xin2 = (F.relu(x) if relu_in else x).clone().requires_grad_(True)
+        gx, = torch.autograd.grad(F.conv_transpose2d(xin2, w, b, stride=s, padding=p), [xin2], dyq)
 
     d = ops.conv_desc(B, IH, IW, Ci, Co, k, s, p, transposed=tr, dtype=bf)
     wf, wd = ops.pack_weights(d, gpu(w))
-    assert wf.dtype == bf
     xg = gpu(nhwc(x)).to(bf) if Ci > 1 else gpu(nhwc(x))
     yg = ops.conv_forward(d, xg, wf, gpu(b), flags=ops.NSG_RELU_IN if relu_in else 0)
     assert yg.dtype == (bf if Co > 1 else torch.float32)
@@ -373,6 +373,9 @@ def test_batchnorm_train_forward_backward(B, C, H, W, relu, res):
     cs = torch.empty(C, device=DEV)
     dxg2, _, _ = ops.bn_backward(xg, ybn, gpu(nhwc(dy)), mean, invstd, gpu(gamma.detach()), dx_colsum=cs)
     _close(dxg2.cpu(), dxg.cpu(), tol=1e-6, what="bn dx (colsum variant)")
+    if relu:   # ReLU mask re-derived from x with the forward's arithmetic: the same mask, bit for bit
+        dxg3, dgg3, dbg3 = ops.bn_backward(xg, None, gpu(nhwc(dy)), mean, invstd, gpu(gamma.detach()), relu_beta=gpu(beta.detach()))
+        assert torch.equal(dxg3, dxg) and torch.equal(dgg3, dgg) and torch.equal(dbg3, dbg)
     want_cs = dxg.double().sum(dim=(0, 1, 2)).cpu()
     assert float((cs.cpu().double() - want_cs).abs().max()) <= 1e-5 * float(dxg.abs().sum(dim=(0, 1, 2)).max()) + 1e-7
     _close(dgg.cpu(), gg, tol=3e-5, what="bn dgamma")
