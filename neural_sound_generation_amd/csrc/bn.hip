@@ -93,21 +93,38 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__rest
     const int c = blockIdx.x * 8 + (tid >> 5);
     double n = 0.0, mu = 0.0, m2 = 0.0;
     if (c < C) {
-        const int per = (nslab + 31) / 32;
+        constexpr int PER_MAX = MAX_SLABS / 32;
+        const int per = (nslab + 31) / 32;          // <= PER_MAX
         const int s0 = j * per, s1 = min(nslab, s0 + per);
+        // all loads first (independent), then the arithmetic: one memory latency instead of 2*per of them
+        float ms[PER_MAX], qs[PER_MAX];
+#pragma unroll
+        for (int i = 0; i < PER_MAX; ++i) {
+            const int sc = min(s0 + i, nslab - 1);   // unconditional (clamped) loads: nothing waits on a branch
+            ms[i] = partial[(size_t)sc * 2 * C + c];
+            qs[i] = partial[(size_t)sc * 2 * C + C + c];
+        }
         double t = 0.0;
-        for (int s = s0; s < s1; ++s) {
-            const int64_t r0 = (int64_t)s * slab_rows;
-            const double ns = (double)(min(M, r0 + slab_rows) - r0);
-            n += ns;
-            t += ns * (double)partial[(size_t)s * 2 * C + c];
+#pragma unroll
+        for (int i = 0; i < PER_MAX; ++i) {
+            const int s = s0 + i;
+            if (i < per && s < s1) {
+                const int64_t r0 = (int64_t)s * slab_rows;
+                const double ns = (double)(min(M, r0 + slab_rows) - r0);
+                n += ns;
+                t += ns * (double)ms[i];
+            }
         }
         if (n > 0.0) mu = t / n;
-        for (int s = s0; s < s1; ++s) {
-            const int64_t r0 = (int64_t)s * slab_rows;
-            const double ns = (double)(min(M, r0 + slab_rows) - r0);
-            const double dl = (double)partial[(size_t)s * 2 * C + c] - mu;
-            m2 += (double)partial[(size_t)s * 2 * C + C + c] + ns * dl * dl;
+#pragma unroll
+        for (int i = 0; i < PER_MAX; ++i) {
+            const int s = s0 + i;
+            if (i < per && s < s1) {
+                const int64_t r0 = (int64_t)s * slab_rows;
+                const double ns = (double)(min(M, r0 + slab_rows) - r0);
+                const double dl = (double)ms[i] - mu;
+                m2 += (double)qs[i] + ns * dl * dl;
+            }
         }
     }
     sn[tid] = n; smu[tid] = mu; sm2[tid] = m2;
@@ -278,10 +295,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restri
     if (c < C) {
         const int per = (nslab + 31) / 32;
         const int b0 = j * per, b1 = min(nslab, b0 + per);
-        for (int s = b0; s < b1; ++s) {
-            s1 += (double)partial[(size_t)s * 2 * C + c];
-            s2 += (double)partial[(size_t)s * 2 * C + C + c];
-        }
+        if (b1 > b0) nsg_strided_sum2(partial + (size_t)b0 * 2 * C + c, partial + (size_t)b0 * 2 * C + C + c, (size_t)2 * C, b1 - b0, s1, s2);
     }
     r1[tid] = s1; r2[tid] = s2;
     __syncthreads();
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(256) void slab_sum_final_kernel(const float *__rest
     if (c < C) {
         const int per = (nslab + 31) / 32;
         const int b0 = j * per, b1 = min(nslab, b0 + per);
-        for (int i = b0; i < b1; ++i) s += (double)partial[(size_t)i * C + c];
+        if (b1 > b0) s = nsg_strided_sum<double>(partial + (size_t)b0 * C + c, (size_t)C, b1 - b0);
     }
     red[tid] = s;
     __syncthreads();

@@ -119,6 +119,7 @@ __global__ void final_mean_kernel(const double *partial, int n, double denom, fl
     __shared__ double red[64];
     const int lane = threadIdx.x;
     double t = 0.0;
+#pragma unroll 8
     for (int i = lane; i < n; i += 64) t += partial[i];
     red[lane] = t;
     __syncthreads();

@@ -36,7 +36,7 @@ namespace {
 constexpr int LDS_PITCH = 36;   // floats per staged row (32 + 4 pad)
 
 template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gather_gemm_kernel(const GatherGemmParams p)
 {
     constexpr int EPV = 16 / (int)sizeof(TI);   // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
     constexpr int KC = 8 * EPV;                 // channels per K-chunk: 128 bytes of a row
@@ -72,13 +72,22 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     const int py = cls >> 1, px = cls & 1;
 
     // ---- per-thread gather rows: row r_j = tid/8 + 32 j ----
+    // Operands are fetched with buffer loads: an offset past the end of the buffer reads as zero, so the conv padding,
+    // ragged row tiles and ragged channel chunks cost one select on the OFFSET instead of selects on the data.
+    constexpr unsigned ES = sizeof(TI);
+    constexpr unsigned OOB = 0xfffffff0u;   // >= any buffer size accepted by the launcher
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI *>(gin), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI *>(gw), 0, (int)p.w_bytes, 0x00020000);
     const int c4 = (tid & 7) * EPV;   // this thread's 16-byte piece inside a chunk, in elements
     const int rsub = tid >> 3;
-    int rbase[AJ];  // element offset of (b, iy0, ix0, 0); may be "negative pixel", guarded by iy/ix tests
-    int riy0[AJ], rix0[AJ];
+    const int ntaps = (MODE == 0) ? p.KH * p.KW : 4;
+    unsigned rbase[AJ];    // BYTE offset of (b, iy0, ix0, c4) (wraps for "negative" pixels; only used when the tap is valid)
+    unsigned tapmask[AJ];  // bit t: tap t of this row lies inside the image
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int m = m0 + rsub + 32 * j;
+        rbase[j] = 0;
+        tapmask[j] = 0;
         if (m < p.M) {
             const int b = m / (p.RH * p.RW);
             const int rem = m - b * (p.RH * p.RW);
@@ -87,14 +96,25 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
             int iy0, ix0;
             if (MODE == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad; }
             else           { iy0 = ry + py;               ix0 = rx + px; }
-            riy0[j] = iy0;
-            rix0[j] = ix0;
-            rbase[j] = ((b * p.IH + iy0) * p.IW + ix0) * p.CI;
-        } else {
-            riy0[j] = -(1 << 28);  // never in range
-            rix0[j] = -(1 << 28);
-            rbase[j] = 0;
+            rbase[j] = (unsigned)(((b * p.IH + iy0) * p.IW + ix0) * p.CI + c4) * ES;
+            const int kwl = (MODE == 0) ? p.KW : 2;
+            unsigned tm = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int kh = t / kwl, kw = t - kh * kwl;
+                const int iy = (MODE == 0) ? iy0 + kh : iy0 - kh;
+                const int ix = (MODE == 0) ? ix0 + kw : ix0 - kw;
+                tm |= (unsigned)((iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW)) << t;
+            }
+            tapmask[j] = tm;
         }
+    }
+    unsigned wbase[BJ];    // BYTE offset of (tap 0, n, c4)
+    unsigned wmask[BJ];    // all ones when column n exists, else zero
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int n = n0 + rsub + 32 * j;
+        wbase[j] = (unsigned)(n * p.CI + c4) * ES;
+        wmask[j] = n < p.CO ? 0xffffffffu : 0u;
     }
     // ---- output row offsets ----
     if (tid < BM) {
@@ -113,56 +133,50 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     }
 
     const int nchunks = (p.CI + KC - 1) / KC;
-    const int ntaps = (MODE == 0) ? p.KH * p.KW : 4;
     const int nit = ntaps * nchunks;
 
-    v4f ra[AJ], rb[BJ];
-    unsigned okmask = 0;  // bit j: ra[j] is a real element; bit 16+j: rb[j] is
+    v4f ra0[AJ], rb0[BJ], ra1[AJ], rb1[BJ];   // two register stages: loads run two chunks ahead of the MFMAs
 
     // state of the NEXT chunk to load (advanced incrementally: no divisions in the loop)
-    int g_c0 = 0, g_kh = 0, g_kw = 0;   // MODE 0: (kh,kw) of the tap; MODE 1: (a,b2) of the class tap
-    auto gload = [&]() {
+    int g_c0 = 0, g_kh = 0, g_kw = 0, g_t = 0;   // MODE 0: (kh,kw) of the tap; MODE 1: (a,b2) of the class tap; g_t = tap number
+    auto gload = [&](v4f (&ra)[AJ], v4f (&rb)[BJ]) {
         int dy, dx, ws;
         if (MODE == 0) { dy = g_kh; dx = g_kw; ws = g_kh * p.KW + g_kw; }
         else           { dy = -g_kh; dx = -g_kw; ws = ((1 - py) + 2 * g_kh) * 4 + (1 - px) + 2 * g_kw; }
         const int c0 = g_c0;
-        const int tapoff = (dy * p.IW + dx) * p.CI + c0 + c4;
-        const int cok = (c0 + c4) < p.CI;
-        unsigned m = 0;
+        const unsigned tap_b = (unsigned)((dy * p.IW + dx) * p.CI + c0) * ES;   // uniform
+        const unsigned wtap_b = (unsigned)(ws * p.CO * p.CI + c0) * ES;         // uniform
+        const bool cok = (c0 + c4) < p.CI;
+        const unsigned sel = cok ? (1u << g_t) : 0u;
+        const unsigned cm = cok ? 0xffffffffu : 0u;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int iy = riy0[j] + dy, ix = rix0[j] + dx;
-            const int ok = cok & (iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW);
-            const int off = ok ? rbase[j] + tapoff : 0;
-            ra[j] = *reinterpret_cast<const v4f *>(gin + off);
-            m |= (unsigned)ok << j;
+            const unsigned off = (tapmask[j] & sel) ? rbase[j] + tap_b : OOB;
+            ra[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int n = n0 + rsub + 32 * j;
-            const int ok = cok & (n < p.CO);
-            const int off = ok ? ((ws * p.CO + n) * p.CI + c0 + c4) : 0;
-            rb[j] = *reinterpret_cast<const v4f *>(gw + off);
-            m |= (unsigned)ok << (16 + j);
+            const unsigned m = wmask[j] & cm;                       // branch-free: (m ? offset : OOB) as a bit select
+            const unsigned off = ((wbase[j] + wtap_b) & m) | (OOB & ~m);
+            rb[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
         }
-        okmask = m;
         // advance to the following chunk
         g_c0 += KC;
         const int wrap = g_c0 >= p.CI;
         g_c0 = wrap ? 0 : g_c0;
         g_kw += wrap;
+        g_t += wrap;
         const int kwlim = (MODE == 0) ? p.KW : 2;
         const int wrap2 = g_kw >= kwlim;
         g_kw = wrap2 ? 0 : g_kw;
         g_kh += wrap2;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const v4f (&ra)[AJ], const v4f (&rb)[BJ]) {
         float *a = As + buf * BM * LDS_PITCH;
         float *b = Bs + buf * BN * LDS_PITCH;
-        const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            v4f v = (okmask >> j) & 1u ? ra[j] : zero;
+            v4f v = ra[j];
             if (RELU) {
                 if constexpr (BF) {   // a bf16 is negative exactly when its bit pattern is a negative int16
                     s16x8 sv = __builtin_bit_cast(s16x8, v);
@@ -176,8 +190,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
             *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = v;
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = (okmask >> (16 + j)) & 1u ? rb[j] : zero;
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = rb[j];
     };
 
     v16f acc[TM][TN];
@@ -221,19 +234,30 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherGemmParams
     unsigned long long st_t0 = 0, st_r0 = 0;
     if (p.stamps) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
-    gload();
-    lstore(0);
+    // Chunk i is computed from LDS buffer i&1 while chunk i+1 waits in registers (stored to the other buffer right
+    // after the MFMAs of chunk i are issued) and chunk i+2 is in flight from memory: a 32x32x16 chunk is only ~512
+    // matrix-pipe cycles, shorter than a global load, so a single register stage would stall every chunk.
+    gload(ra0, rb0);                  // chunk 0
+    if (nit > 1) gload(ra1, rb1);     // chunk 1
+    lstore(0, ra0, rb0);
     __syncthreads();
-
-    // steady state: straight-line body, the scheduler overlaps staging with the MFMAs
-    for (int it = 0; it + 1 < nit; ++it) {
-        const int cur = it & 1;
-        gload();
-        compute(cur);
-        lstore(cur ^ 1);
+    int it = 0;
+    for (; it + 2 < nit; it += 2) {   // straight-line body (two chunks): buffer 0 holds chunk it, ra1/rb1 hold chunk it+1
+        gload(ra0, rb0);              // chunk it+2
+        compute(0);
+        lstore(1, ra1, rb1);
+        __syncthreads();
+        gload(ra1, rb1);              // chunk it+3 (past the end: every offset is out of range, reads zeros, never stored)
+        compute(1);
+        lstore(0, ra0, rb0);
         __syncthreads();
     }
-    compute((nit - 1) & 1);
+    compute(0);
+    if (it + 1 < nit) {
+        lstore(1, ra1, rb1);
+        __syncthreads();
+        compute(1);
+    }
     if (p.stamps && tid == 0) {   // diagnostics: never read by any kernel
         const int bid = blockIdx.y * gridDim.x + blockIdx.x;
         p.stamps[2 * bid] = __builtin_amdgcn_s_memtime() - st_t0;
@@ -397,10 +421,19 @@ int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
     return (int)nsg_cdiv(p.M, 128) * (p.mode == 0 ? 1 : 4);
 }
 
-int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s)
+int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
 {
+    GatherGemmParams p = p_in;
     if (p.M <= 0) return NSG_OK;
     const int epv = p.in_dtype == NSG_BF16 ? 8 : 4;
+    const uint64_t es = p.in_dtype == NSG_BF16 ? 2 : 4;
+    const uint64_t in_bytes = (uint64_t)p.B * p.IH * p.IW * p.CI * es;
+    const uint64_t w_bytes = (uint64_t)(p.mode == 0 ? p.KH * p.KW : 16) * p.CO * p.CI * es;
+    if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull)   // 32-bit byte offsets; 0xfffffff0 is the kernel's "reads as zero" offset
+        return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: operand of %llu bytes (limit 4 GiB per tensor: split the batch)", (unsigned long long)in_bytes);
+    if ((p.mode == 0 ? p.KH * p.KW : 4) > 32) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: more than 32 taps");
+    p.in_bytes = (unsigned)in_bytes;
+    p.w_bytes = (unsigned)w_bytes;
     if (p.CI % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of %d", p.CI, epv);
     if (!nsg_aligned16(p.in) || !nsg_aligned16(p.w)) return nsg_fail(NSG_E_INVALID, "gather_gemm: operands must be 16-byte aligned");
     if (p.in_dtype == NSG_F32 && p.out_dtype == NSG_F32) return launch_typed<float, float>(p, s);

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         if (e < total) {
             const int chunk = (nslab + split - 1) / split;
             const int s0 = sub * chunk, s1 = min(nslab, s0 + chunk);
-            for (int sl = s0; sl < s1; ++sl) sacc += partial[(size_t)sl * total + e];
+            if (s1 > s0) sacc = nsg_strided_sum<float>(partial + (size_t)s0 * total + e, (size_t)total, s1 - s0);
         }
         if (split > 1) {
             red[tid] = sacc;

@@ -53,6 +53,50 @@ template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ void put(bf16_t *p, float v) { *p = nsg_f2bf(v); }
 };
 
+// Fixed-order sum of n floats p[0], p[stride], p[2*stride], ... : the loads are issued 16 at a time (the
+// finalize kernels are otherwise a chain of dependent global-load latencies), the adds stay in index order.
+template <typename ACC>
+__device__ __forceinline__ ACC nsg_strided_sum(const float *__restrict__ p, size_t stride, int n)
+{
+    ACC s = (ACC)0;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[(size_t)(i + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += (ACC)v[k];
+    }
+    if (i + 8 <= n) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(i + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (ACC)v[k];
+        i += 8;
+    }
+    for (; i < n; ++i) s += (ACC)p[(size_t)i * stride];
+    return s;
+}
+
+// two arrays at once (their loads share the latency)
+__device__ __forceinline__ void nsg_strided_sum2(const float *__restrict__ p, const float *__restrict__ q, size_t stride, int n,
+                                                 double &sp, double &sq)
+{
+    double a = 0.0, b = 0.0;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+        float v[16], w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = p[(size_t)(i + k) * stride]; w[k] = q[(size_t)(i + k) * stride]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += (double)v[k]; b += (double)w[k]; }
+    }
+    for (; i < n; ++i) { a += (double)p[(size_t)i * stride]; b += (double)q[(size_t)i * stride]; }
+    sp = a;
+    sq = b;
+}
+
 // thread-local error text (never thrown across the ABI)
 void nsg_set_error(const char *fmt, ...);
 int nsg_fail(int code, const char *fmt, ...);
@@ -119,6 +163,7 @@ struct GatherGemmParams {
     int M;       // rows per class = B*RH*RW
     int RH, RW;  // row grid: conv -> (OH,OW); transposed -> (ceil(OH/2), ceil(OW/2))
     int flags;   // NSG_RELU_IN | NSG_TANH_OUT
+    unsigned in_bytes, w_bytes;  // sizes of `in` and `w` (filled in by nsg_launch_gather_gemm; buffer-load range checks)
     unsigned long long *stamps;  // diagnostics only: per block (shader cycles, 100 MHz ticks) spent in the main loop
     float *stats;  // optional [n_row_tiles][3][CO]: per row tile (valid-row count, mean, M2 about it) of the OUTPUT
 };

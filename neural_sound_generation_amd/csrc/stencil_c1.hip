@@ -128,13 +128,15 @@ __global__ __launch_bounds__(256) void c1_stencil_fwd_kernel(const float *__rest
 }
 
 // partial[block][c][17]: 16 tap sums + the column sum of t, over the block's tiles, reduced over the block's pixel
-// slots in slot order (fixed order: bitwise reproducible)
+// slots in slot order (fixed order: bitwise reproducible).  The stream of t is the whole cost: four pixels' loads
+// are in flight per thread before their multiply-adds start.
 template <typename TI, bool RELU>
 __global__ __launch_bounds__(256) void c1_stencil_wgrad_kernel(const float *__restrict__ img, const TI *__restrict__ t,
                                                                float *__restrict__ partial, const C1Geom g)
 {
     __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [68][256]
+    __shared__ float red[17 * 256];
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
     const int G = g.C >> 2;
     const int SL = 256 / G;
@@ -158,52 +160,58 @@ __global__ __launch_bounds__(256) void c1_stencil_wgrad_kernel(const float *__re
         if (!active) continue;
         const int npx = min(TW, g.LW - ox0);
         const TI *trow = t + (((size_t)b * g.LH + ly) * g.LW + ox0) * g.C + c0;
-        for (int j = sl; j < npx; j += SL) {
-            float tv[4];
-            if constexpr (sizeof(TI) == 4) {
-                const v4f v = *reinterpret_cast<const v4f *>(trow + (size_t)j * g.C);
-                tv[0] = v.x; tv[1] = v.y; tv[2] = v.z; tv[3] = v.w;
-            } else {
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                const v2u pk = *reinterpret_cast<const v2u *>(trow + (size_t)j * g.C);
-                const unsigned u0 = pk.x, u1 = pk.y;
-                tv[0] = nsg_bitsf(u0 << 16); tv[1] = nsg_bitsf(u0 & 0xffff0000u);
-                tv[2] = nsg_bitsf(u1 << 16); tv[3] = nsg_bitsf(u1 & 0xffff0000u);
+        for (int j0 = sl; j0 < npx; j0 += 4 * SL) {
+            float tv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * SL;
+                const int jc = j < npx ? j : j0;          // clamped: always a valid address
+                if constexpr (sizeof(TI) == 4) {
+                    const v4f v = *reinterpret_cast<const v4f *>(trow + (size_t)jc * g.C);
+                    tv[u][0] = v.x; tv[u][1] = v.y; tv[u][2] = v.z; tv[u][3] = v.w;
+                } else {
+                    const v2u pk = *reinterpret_cast<const v2u *>(trow + (size_t)jc * g.C);
+                    const unsigned u0 = pk.x, u1 = pk.y;
+                    tv[u][0] = nsg_bitsf(u0 << 16); tv[u][1] = nsg_bitsf(u0 & 0xffff0000u);
+                    tv[u][2] = nsg_bitsf(u1 << 16); tv[u][3] = nsg_bitsf(u1 & 0xffff0000u);
+                }
             }
-            if (RELU) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) tv[c] = fmaxf(tv[c], 0.f);
-            }
-            v2f tp[8];
-            read_taps(patch[buf], j, tp);
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * SL;
+                if (j < npx) {
+                    v2f tp[8];
+                    read_taps(patch[buf], j, tp);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const v2f tc = {tv[c], tv[c]};
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = RELU ? fmaxf(tv[u][c], 0.f) : tv[u][c];
+                        const v2f tc = {x, x};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[c][k] = __builtin_elementwise_fma(tc, tp[k], acc[c][k]);
-                cs[c] += tv[c];
+                        for (int k = 0; k < 8; ++k) acc[c][k] = __builtin_elementwise_fma(tc, tp[k], acc[c][k]);
+                        cs[c] += x;
+                    }
+                }
             }
         }
     }
-    __syncthreads();
-    // ---- reduce over the block's slots: red[v][tid], v = c*17 + tap (tap 16 = column sum) ----
+    // ---- reduce over the block's slots, one of the thread's 4 channels per pass: red[v][tid], v = tap (16 = column sum) ----
+    float *dst = partial + (size_t)blockIdx.x * g.C * 17;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            red[(c * 17 + 2 * k) * 256 + tid] = active ? acc[c][k].x : 0.f;
-            red[(c * 17 + 2 * k + 1) * 256 + tid] = active ? acc[c][k].y : 0.f;
+            red[(2 * k) * 256 + tid] = active ? acc[c][k].x : 0.f;
+            red[(2 * k + 1) * 256 + tid] = active ? acc[c][k].y : 0.f;
         }
-        red[(c * 17 + 16) * 256 + tid] = active ? cs[c] : 0.f;
-    }
-    __syncthreads();
-    float *dst = partial + (size_t)blockIdx.x * g.C * 17;
-    for (int e = tid; e < G * 68; e += 256) {      // e = v * G + cg'
-        const int v = e / G, cgp = e - v * G;
-        float s = 0.f;
-        for (int q = 0; q < SL; ++q) s += red[v * 256 + q * G + cgp];
-        const int c = v / 17, tap = v - c * 17;
-        dst[(size_t)(cgp * 4 + c) * 17 + tap] = s;
+        red[16 * 256 + tid] = active ? cs[c] : 0.f;
+        __syncthreads();
+        for (int e = tid; e < G * 17; e += 256) {      // e = v * G + cg'
+            const int v = e / G, cgp = e - v * G;
+            float s = 0.f;
+            for (int q = 0; q < SL; ++q) s += red[v * 256 + q * G + cgp];
+            dst[(size_t)(cgp * 4 + c) * 17 + v] = s;
+        }
     }
 }
 
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void c1_stencil_wgrad_final_kernel(const float
     if (e < total) {
         const int per = (nblocks + 7) / 8;
         const int b0 = j * per, b1 = min(nblocks, b0 + per);
-        for (int b = b0; b < b1; ++b) s += (double)partial[(size_t)b * total + e];
+        if (b1 > b0) s = nsg_strided_sum<double>(partial + (size_t)b0 * total + e, (size_t)total, b1 - b0);
     }
     red[tid] = s;
     __syncthreads();
@@ -243,7 +251,7 @@ C1Geom make_geom(int B, int LH, int LW, int HH, int WW, int C)
     return g;
 }
 
-constexpr int WGRAD_BLOCKS = 512;
+constexpr int WGRAD_BLOCKS = 1024;
 
 }  // namespace
 
@@ -272,20 +280,7 @@ int nsg_launch_c1_stencil_wgrad(const float *img, const void *t, int t_dtype, in
     int blocks = g.ntiles < WGRAD_BLOCKS ? g.ntiles : WGRAD_BLOCKS;
     if (blocks < 1) blocks = 1;
     float *partial = reinterpret_cast<float *>(ws);
-    const size_t lds = (size_t)68 * 256 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *fns[4] = {reinterpret_cast<const void *>(&c1_stencil_wgrad_kernel<float, false>),
-                              reinterpret_cast<const void *>(&c1_stencil_wgrad_kernel<float, true>),
-                              reinterpret_cast<const void *>(&c1_stencil_wgrad_kernel<bf16_t, false>),
-                              reinterpret_cast<const void *>(&c1_stencil_wgrad_kernel<bf16_t, true>)};
-        for (const void *f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return nsg_fail((int)e, "c1_stencil_wgrad: cannot reserve %zu bytes of LDS", lds);
-        }
-        attr_set = true;
-    }
-#define NSG_C1W(TI, R) hipLaunchKernelGGL((c1_stencil_wgrad_kernel<TI, R>), dim3(blocks), dim3(256), lds, s, img, reinterpret_cast<const TI *>(t), partial, g)
+#define NSG_C1W(TI, R) hipLaunchKernelGGL((c1_stencil_wgrad_kernel<TI, R>), dim3(blocks), dim3(256), 0, s, img, reinterpret_cast<const TI *>(t), partial, g)
     if (t_dtype == NSG_BF16) { if (relu_t) NSG_C1W(bf16_t, true); else NSG_C1W(bf16_t, false); }
     else                     { if (relu_t) NSG_C1W(float, true);  else NSG_C1W(float, false); }
 #undef NSG_C1W
