@@ -167,6 +167,15 @@ NSG_API int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, cons
 NSG_API int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, int32_t flags,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the rest of a ResBlock's input gradient folded into the kernel's store:
+ *   dx = (conv_dgrad(dy) + add) * (relu_x > 0)
+ * add (or NULL): the gradient arriving over the skip connection; relu_x (or NULL): the ReLU'd tensor the
+ * convolution read (src/models.py:149,158: x is overwritten by relu(x), so mask = relu_x > 0).  Both are laid
+ * out like dx.  Replaces nsg_conv_dgrad + nsg_relu_backward_add (one write and one read of dx less). */
+NSG_API int nsg_conv_dgrad_relu_add(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, const void *add,
+                                    const void *relu_x, void *dx, int32_t flags, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 /* dw (reference weight layout, fully overwritten) and dbias (or NULL) given x and dy.
  * flags: NSG_RELU_IN treats x as max(0,x) (the fused preceding ReLU).  Deterministic. */
 NSG_API int nsg_conv_wgrad(const nsg_conv_desc *d, const void *x, const void *dy, float *dw, float *dbias,

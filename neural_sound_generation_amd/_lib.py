@@ -51,6 +51,7 @@ _SIGS = {
     "nsg_conv_forward": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_conv_forward_bnstats": (None, [_D, _P, _P, _P, _P, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_conv_dgrad": (None, [_D, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_conv_dgrad_relu_add": (None, [_D, _P, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_conv_wgrad": (None, [_D, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "nsg_bn_stats": (None, [_P, c_int64, c_int32, c_int32, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),

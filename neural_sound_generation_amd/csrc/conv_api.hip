@@ -441,6 +441,12 @@ int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, const void *
 int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, void *dx, int32_t flags, void *workspace,
                    size_t workspace_bytes, void *stream)
 {
+    return nsg_conv_dgrad_relu_add(d, dy, w_dgrad, nullptr, nullptr, dx, flags, workspace, workspace_bytes, stream);
+}
+
+int nsg_conv_dgrad_relu_add(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, const void *add, const void *relu_x,
+                            void *dx, int32_t flags, void *workspace, size_t workspace_bytes, void *stream)
+{
     (void)flags;
     const int kind = classify(d, "nsg_conv_dgrad");
     if (kind < 0) return kind;
@@ -450,6 +456,7 @@ int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, 
         // roles swap: the gradient of a conv is a transposed conv and vice versa
         GatherGemmParams p = {};
         p.in = dy; p.w = w_dgrad; p.bias = nullptr; p.out = dx;
+        p.epi_add = add; p.epi_mask = relu_x;
         p.in_dtype = d->dtype; p.out_dtype = d->dtype;
         p.B = d->B; p.IH = d->OH; p.IW = d->OW; p.CI = d->C_out;
         p.OH = d->IH; p.OW = d->IW; p.CO = d->C_in;
@@ -466,6 +473,7 @@ int nsg_conv_dgrad(const nsg_conv_desc *d, const void *dy, const void *w_dgrad, 
         p.stamps = g_debug_stamps;
         return nsg_launch_gather_gemm(p, s);
     }
+    NSG_REQUIRE(!add && !relu_x, NSG_E_UNSUPPORTED, "nsg_conv_dgrad_relu_add: not available for the single-channel layers");
     NSG_REQUIRE(workspace && workspace_bytes >= patches_bytes(d), NSG_E_WORKSPACE, "nsg_conv_dgrad: workspace too small");
     const int64_t Mp = lowres_pixels(d);
     if (kind == K_CONVT_C1) {

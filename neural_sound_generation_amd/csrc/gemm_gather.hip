@@ -290,31 +290,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int e = 0; e < EPO; ++e) bv[e] = (p.bias && col + e < p.CO) ? p.bias[col + e] : 0.f;
     const bool full_vec = vec_store && col + EPO - 1 < p.CO;
+    const TO *__restrict__ epi_add = reinterpret_cast<const TO *>(p.epi_add);     // (launcher: only with full 16-byte pieces)
+    const TO *__restrict__ epi_mask = reinterpret_cast<const TO *>(p.epi_mask);
     if (col < p.CO) {
-        for (int row = tid / NV; row < BM; row += 256 / NV) {
-            const int off = rowoff[row];
-            if (off < 0) continue;
-            float v[EPO];
+        constexpr int RSTEP = 256 / NV;          // tile rows covered per pass of the block
+        constexpr int RI = BM / RSTEP;           // passes
+        constexpr int GRP = RI < 8 ? RI : 8;     // the fused add / mask operands of GRP passes are fetched together
+        const bool fuse_add = full_vec && epi_add != nullptr, fuse_mask = full_vec && epi_mask != nullptr;
+        for (int g0 = 0; g0 < RI; g0 += GRP) {
+            v4f addv[GRP], maskv[GRP];
+            if (fuse_add) {
 #pragma unroll
-            for (int e = 0; e < EPO; e += 4) {
-                const v4f t = *reinterpret_cast<const v4f *>(Cs + row * CP + cq + e);
-                v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+                for (int i = 0; i < GRP; ++i) {
+                    const int off = rowoff[tid / NV + (g0 + i) * RSTEP];
+                    addv[i] = *reinterpret_cast<const v4f *>(epi_add + (size_t)(off < 0 ? 0 : off) + col);   // clamped, unconditional
+                }
+            }
+            if (fuse_mask) {
+#pragma unroll
+                for (int i = 0; i < GRP; ++i) {
+                    const int off = rowoff[tid / NV + (g0 + i) * RSTEP];
+                    maskv[i] = *reinterpret_cast<const v4f *>(epi_mask + (size_t)(off < 0 ? 0 : off) + col);
+                }
             }
 #pragma unroll
-            for (int e = 0; e < EPO; ++e) v[e] += bv[e];
-            if (tanh_out) {
+            for (int i = 0; i < GRP; ++i) {
+                const int row = tid / NV + (g0 + i) * RSTEP;
+                const int off = rowoff[row];
+                if (off < 0) continue;
+                float v[EPO];
 #pragma unroll
-                for (int e = 0; e < EPO; ++e) v[e] = tanhf(v[e]);
-            }
+                for (int e = 0; e < EPO; e += 4) {
+                    const v4f t = *reinterpret_cast<const v4f *>(Cs + row * CP + cq + e);
+                    v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
+                }
 #pragma unroll
-            for (int e = 0; e < EPO; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];   // (a select keeps NaNs visible)
-            TO *dst = gout + (size_t)off + col;
-            if (full_vec) {
-                Elem<TO>::store16(dst, v);
-            } else {
+                for (int e = 0; e < EPO; ++e) v[e] += bv[e];
+                if (tanh_out) {
 #pragma unroll
-                for (int e = 0; e < EPO; ++e)
-                    if (col + e < p.CO) Elem<TO>::put(dst + e, v[e]);
+                    for (int e = 0; e < EPO; ++e) v[e] = tanhf(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < EPO; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];   // (a select keeps NaNs visible)
+                if (fuse_add) {      // + the skip-path gradient (the ResBlock's residual add, backward)
+                    float t[EPO];
+                    Elem<TO>::unpack16(addv[i], t);
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e) v[e] += t[e];
+                }
+                if (fuse_mask) {     // gradient through the ReLU whose OUTPUT is epi_mask (x > 0 <=> relu(x) > 0)
+                    float t[EPO];
+                    Elem<TO>::unpack16(maskv[i], t);
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+                }
+                TO *dst = gout + (size_t)off + col;
+                if (full_vec) {
+                    Elem<TO>::store16(dst, v);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPO; ++e)
+                        if (col + e < p.CO) Elem<TO>::put(dst + e, v[e]);
+                }
             }
         }
     }
@@ -432,6 +469,11 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
     if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull)   // 32-bit byte offsets; 0xfffffff0 is the kernel's "reads as zero" offset
         return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: operand of %llu bytes (limit 4 GiB per tensor: split the batch)", (unsigned long long)in_bytes);
     if ((p.mode == 0 ? p.KH * p.KW : 4) > 32) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: more than 32 taps");
+    if (p.epi_add || p.epi_mask) {
+        const int epo = p.out_dtype == NSG_BF16 ? 8 : 4;
+        if (p.CO % epo != 0 || !nsg_aligned16(p.out) || (p.epi_add && !nsg_aligned16(p.epi_add)) || (p.epi_mask && !nsg_aligned16(p.epi_mask)))
+            return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: the fused add / ReLU-mask epilogue needs C_out %% %d == 0 and 16-byte aligned tensors", epo);
+    }
     p.in_bytes = (unsigned)in_bytes;
     p.w_bytes = (unsigned)w_bytes;
     if (p.CI % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of %d", p.CI, epv);

@@ -293,18 +293,23 @@ __device__ __forceinline__ s16x4 lds_tr_read(const bf16_t *p)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
 }
 
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void wgrad_gemm_bf16(const WgradParams p)
+template <int WM, int WN, int TM, int TN, bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_gemm_bf16(const WgradParams p)
 {
     constexpr int TA = WM * TM * 32;
     constexpr int TC = WN * TN * 32;
     constexpr int PP = TA + 32;                          // LDS row pitch in bf16 elements (2*TA + 64 bytes)
     constexpr int QP = TC + 32;
     constexpr int PA8 = TA / 8, QC8 = TC / 8;            // 16-byte pieces per pixel row
-    constexpr int PJ = (KPB * PA8 + 255) / 256;
-    constexpr int QJ = (KPB * QC8 + 255) / 256;
+    constexpr int PJ = KPB * PA8 / 256;
+    constexpr int QJ = KPB * QC8 / 256;
+    static_assert(KPB * PA8 % 256 == 0 && KPB * QC8 % 256 == 0, "every thread stages the same number of pieces");
     const bf16_t *__restrict__ gP = reinterpret_cast<const bf16_t *>(p.P);
     const bf16_t *__restrict__ gQ = reinterpret_cast<const bf16_t *>(p.Q);
+    // buffer loads: an offset past the end reads as zero (slab tails, conv padding, ragged channel tiles)
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(gP), 0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(gQ), 0, (int)p.q_bytes, 0x00020000);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bf16_t *Ps = reinterpret_cast<bf16_t *>(smem);       // [2][KPB][PP]
@@ -330,72 +335,57 @@ __global__ __launch_bounds__(256) void wgrad_gemm_bf16(const WgradParams p)
     const int mend = min(p.Mp, mbeg + p.slab_rows);
     const int nchunk = (mend - mbeg + KPB - 1) / KPB;
 
-    v4f rp[PJ], rq[QJ];
-    unsigned okmask = 0;
+    // this thread's pieces: piece j of P is (pixel ppix + pstep*j, channels pa8..pa8+7); likewise Q
+    constexpr int PSTEP = 256 / PA8, QSTEP = 256 / QC8;
+    const int ppix = tid / PA8, pa8 = (tid % PA8) * 8;
+    const int qpix = tid / QC8, qc8 = (tid % QC8) * 8;
+    const bool pa_ok = (a0 + pa8) < p.A, qc_ok = (c0 + qc8) < p.C;
+    const int yoff = kh - p.pad, xoff = kw - p.pad;
+
+    v4f rp0[PJ], rq0[QJ], rp1[PJ], rq1[QJ];   // two register stages (loads run two chunks ahead of the MFMAs)
     int g_mb = mbeg;
 
-    auto gload = [&]() {
+    auto gload = [&](v4f (&rp)[PJ], v4f (&rq)[QJ]) {
         const int mb = g_mb;
-        unsigned mk = 0;
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const int f = tid + 256 * j;
-            const int pix = f / PA8;
-            const int a8 = (f - pix * PA8) * 8;
-            const int m = mb + pix;
-            const int ok = (pix < KPB) & (m < mend) & ((a0 + a8) < p.A);
-            const size_t off = ok ? ((size_t)m * p.A + a0 + a8) : 0;
-            rp[j] = *reinterpret_cast<const v4f *>(gP + off);
-            mk |= (unsigned)ok << j;
+            const int m = mb + ppix + PSTEP * j;
+            const bool ok = pa_ok & (m < mend);
+            const unsigned off = ok ? (unsigned)(m * p.A + a0 + pa8) * 2u : OOB;
+            rp[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_p, (int)off, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < QJ; ++j) {
-            const int f = tid + 256 * j;
-            const int pix = f / QC8;
-            const int c8 = (f - pix * QC8) * 8;
-            const int m = mb + pix;
+            const int m = mb + qpix + QSTEP * j;
             const int mm = m < mend ? m : mbeg;
             const int b = nsg_div(mm, p.div_phw);
             const int rem = mm - b * (p.PH * p.PW);
             const int py = nsg_div(rem, p.div_pw);
             const int px = rem - py * p.PW;
-            const int qy = py * p.stride - p.pad + kh;
-            const int qx = px * p.stride - p.pad + kw;
-            const int ok = (pix < KPB) & (m < mend) & ((c0 + c8) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
-            const size_t off = ok ? (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + c8) : 0;
-            rq[j] = *reinterpret_cast<const v4f *>(gQ + off);
-            mk |= (unsigned)ok << (16 + j);
+            const int qy = py * p.stride + yoff;
+            const int qx = px * p.stride + xoff;
+            const bool ok = qc_ok & (m < mend) & ((unsigned)qy < (unsigned)p.QH) & ((unsigned)qx < (unsigned)p.QW);
+            const unsigned off = ok ? (unsigned)(((b * p.QH + qy) * p.QW + qx) * p.C + c0 + qc8) * 2u : OOB;
+            rq[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_q, (int)off, 0, 0));
         }
-        okmask = mk;
         g_mb += KPB;
     };
-    auto relu8 = [](v4f v) {   // bf16 ReLU: a bf16 is negative exactly when its bit pattern is a negative int16
+    // bf16 ReLU: a bf16 is negative exactly when its bit pattern is a negative int16; floor = 0 (ReLU) or INT16_MIN (identity)
+    const short pfl = p.relu_p ? (short)0 : (short)-32768, qfl = p.relu_q ? (short)0 : (short)-32768;
+    auto floor8 = [](v4f v, short fl) {
         s16x8 sv = __builtin_bit_cast(s16x8, v);
-        const s16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        return __builtin_bit_cast(v4f, __builtin_elementwise_max(sv, z8));
+        const s16x8 f8 = {fl, fl, fl, fl, fl, fl, fl, fl};
+        return __builtin_bit_cast(v4f, __builtin_elementwise_max(sv, f8));
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const v4f (&rp)[PJ], const v4f (&rq)[QJ]) {
         bf16_t *ps = Ps + buf * KPB * PP;
         bf16_t *qs = Qs + buf * KPB * QP;
-        const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int f = tid + 256 * j;
-            if (f >= KPB * PA8) continue;
-            const int pix = f / PA8, a8 = (f - pix * PA8) * 8;
-            v4f v = (okmask >> j) & 1u ? rp[j] : zero;
-            if (p.relu_p) v = relu8(v);
-            *reinterpret_cast<v4f *>(ps + pix * PP + a8) = v;
-        }
+        for (int j = 0; j < PJ; ++j)
+            *reinterpret_cast<v4f *>(ps + (ppix + PSTEP * j) * PP + pa8) = RELU ? floor8(rp[j], pfl) : rp[j];
 #pragma unroll
-        for (int j = 0; j < QJ; ++j) {
-            const int f = tid + 256 * j;
-            if (f >= KPB * QC8) continue;
-            const int pix = f / QC8, c8 = (f - pix * QC8) * 8;
-            v4f v = (okmask >> (16 + j)) & 1u ? rq[j] : zero;
-            if (p.relu_q) v = relu8(v);
-            *reinterpret_cast<v4f *>(qs + pix * QP + c8) = v;
-        }
+        for (int j = 0; j < QJ; ++j)
+            *reinterpret_cast<v4f *>(qs + (qpix + QSTEP * j) * QP + qc8) = RELU ? floor8(rq[j], qfl) : rq[j];
     };
 
     v16f acc[TM][TN];
@@ -434,18 +424,29 @@ __global__ __launch_bounds__(256) void wgrad_gemm_bf16(const WgradParams p)
         }
     };
 
+    // chunk i computed from LDS buffer i&1, chunk i+1 waiting in registers, chunk i+2 in flight (see gather_gemm)
     if (nchunk > 0) {
-        gload();
-        lstore(0);
+        gload(rp0, rq0);
+        if (nchunk > 1) gload(rp1, rq1);
+        lstore(0, rp0, rq0);
         __syncthreads();
-        for (int ch = 0; ch + 1 < nchunk; ++ch) {
-            const int cur = ch & 1;
-            gload();
-            compute(cur);
-            lstore(cur ^ 1);
+        int ch = 0;
+        for (; ch + 2 < nchunk; ch += 2) {
+            gload(rp0, rq0);          // chunk ch+2
+            compute(0);
+            lstore(1, rp1, rq1);
+            __syncthreads();
+            gload(rp1, rq1);          // chunk ch+3 (past the slab: every row fails m < mend, reads zeros, never stored)
+            compute(1);
+            lstore(0, rp0, rq0);
             __syncthreads();
         }
-        compute((nchunk - 1) & 1);
+        compute(0);
+        if (ch + 1 < nchunk) {
+            lstore(1, rp1, rq1);
+            __syncthreads();
+            compute(1);
+        }
     }
 
     const int ntaps = p.KH * p.KW;
@@ -554,12 +555,15 @@ int launch_wg_bf16(const WgradParams &p, int nslab, hipStream_t s)
     dim3 grid(nslab, ntaps, tiles);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
+        for (const void *f : {reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false>),
+                              reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
+        }
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN>), grid, dim3(256), lds, s, p);
+    if (p.relu_p || p.relu_q) hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN, true>), grid, dim3(256), lds, s, p);
+    else                      hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN, false>), grid, dim3(256), lds, s, p);
     return nsg_check_launch("wgrad_gemm_bf16");
 }
 
@@ -604,6 +608,12 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     p.slab_rows = sp.slab_rows;
     p.stamps = g_wgrad_stamps;
     p.stagger = g_wgrad_stagger;
+    if (!p.onehot && p.dtype == NSG_BF16) {   // 32-bit byte offsets in the bf16 kernel's buffer loads
+        const uint64_t pb = (uint64_t)p.Mp * p.A * 2, qb = (uint64_t)p.B * p.QH * p.QW * p.C * 2;
+        if (pb >= 0xfffffff0ull || qb >= 0xfffffff0ull) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: operand larger than 4 GiB: split the batch");
+        p.p_bytes = (unsigned)pb;
+        p.q_bytes = (unsigned)qb;
+    }
     p.div_pw = nsg_fastdiv((uint32_t)p.PW);
     p.div_phw = nsg_fastdiv((uint32_t)p.PH * (uint32_t)p.PW);
     int rc;

@@ -26,16 +26,17 @@ __device__ __forceinline__ float nsg_bf2f(bf16_t h) { return __builtin_bit_cast(
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int N = 4;
-    static __device__ __forceinline__ void load16(const float *p, float *o) { const v4f v = *reinterpret_cast<const v4f *>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void unpack16(const v4f v, float *o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void load16(const float *p, float *o) { unpack16(*reinterpret_cast<const v4f *>(p), o); }
     static __device__ __forceinline__ void store16(float *p, const float *o) { v4f v = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<v4f *>(p) = v; }
     static __device__ __forceinline__ float get(const float *p) { return *p; }
     static __device__ __forceinline__ void put(float *p, float v) { *p = v; }
 };
 template <> struct Elem<bf16_t> {
     static constexpr int N = 8;
-    static __device__ __forceinline__ void load16(const bf16_t *p, float *o)
+    static __device__ __forceinline__ void load16(const bf16_t *p, float *o) { unpack16(*reinterpret_cast<const v4f *>(p), o); }
+    static __device__ __forceinline__ void unpack16(const v4f raw, float *o)
     {
-        const v4f raw = *reinterpret_cast<const v4f *>(p);
         const float r0 = raw.x, r1 = raw.y, r2 = raw.z, r3 = raw.w;
         const unsigned u[4] = {nsg_fbits(r0), nsg_fbits(r1), nsg_fbits(r2), nsg_fbits(r3)};
 #pragma unroll
@@ -163,6 +164,8 @@ struct GatherGemmParams {
     int M;       // rows per class = B*RH*RW
     int RH, RW;  // row grid: conv -> (OH,OW); transposed -> (ceil(OH/2), ceil(OW/2))
     int flags;   // NSG_RELU_IN | NSG_TANH_OUT
+    const void *epi_add;   // optional, laid out like `out` (elements of out_dtype): out = acc + bias + epi_add ...
+    const void *epi_mask;  // optional, laid out like `out`: ... then zeroed where epi_mask <= 0 (gradient through a ReLU)
     unsigned in_bytes, w_bytes;  // sizes of `in` and `w` (filled in by nsg_launch_gather_gemm; buffer-load range checks)
     unsigned long long *stamps;  // diagnostics only: per block (shader cycles, 100 MHz ticks) spent in the main loop
     float *stats;  // optional [n_row_tiles][3][CO]: per row tile (valid-row count, mean, M2 about it) of the OUTPUT
@@ -183,6 +186,7 @@ struct WgradParams {
     int slab_rows;  // multiple of 32
     int relu_p, relu_q, onehot;
     FastDiv div_pw, div_phw;   // filled in by nsg_launch_wgrad
+    unsigned p_bytes, q_bytes; // sizes of P and Q in bytes (filled in by nsg_launch_wgrad; buffer-load range checks)
     unsigned long long *stamps;  // diagnostics only
     int stagger;                 // s_sleep units (64 cycles) the second-dispatched half of the grid waits at start
 };

@@ -164,8 +164,7 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     dw1, _ = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, dw=o[0], want_bias=False)   # x is the stored relu(x)
     dx = None
     if need_dx:
-        dr = ops.conv_dgrad(d1, dh1, wd1)
-        dx = ops.relu_backward_add(dy, dr, x)
+        dx = ops.conv_dgrad(d1, dh1, wd1, add=dy, relu_x=x)    # (dgrad + skip-path gradient) * (x > 0), one kernel
     return dx, [dw1, dbias1, dg1, db1n, dw2, dbias2, dg2, db2n]
 
 
@@ -239,8 +238,7 @@ def decoder_backward(dxt, saved, P: DecoderParams, need_dz: bool = True, dxt_is_
     dbT = o[17] if o[17] is not None else torch.empty(u.shape[-1], dtype=torch.float32, device=u.device)
     du, dg4, dbe4 = ops.bn_backward(u, None, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19], dx_colsum=dbT, relu_beta=P.bn4.bias)
     dwT, _ = ops.conv_wgrad(dT, r1, du, P.convt3.weight.shape, dw=o[16], want_bias=False)   # r1 is stored ReLU'd
-    dr1_pre = ops.conv_dgrad(dT, du, wdT)
-    dr1 = ops.relu_backward_add(dr1_pre, None, r1)
+    dr1 = ops.conv_dgrad(dT, du, wdT, relu_x=r1)               # decoder.2 ReLU's mask applied in the dgrad store
     dr0, g1 = resblock_backward(dr1, s1, P.res1, gout=o[8:16] if gout is not None else None)
     dzq, g0 = resblock_backward(dr0, s0, P.res0, need_dx=need_dz, gout=o[0:8] if gout is not None else None)
     return dzq, g0 + g1 + [dwT, dbT, dg4, dbe4, dw6, db6]

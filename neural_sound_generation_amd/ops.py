@@ -261,7 +261,8 @@ def conv_forward_bnstats(d: ConvDesc, x, w_fwd, bias, flags=0, running_mean=None
     return y, mean, invstd
 
 
-def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
+def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None, add=None, relu_x=None):
+    """dx = conv_dgrad(dy); with add / relu_x: dx = (conv_dgrad(dy) + add) * (relu_x > 0) in the same kernel."""
     _chk(dy, "dy", _out_dtype(d))
     if tuple(dy.shape) != (d.B, d.OH, d.OW, d.C_out):
         raise _lib.NsgError(f"conv_dgrad: dy shape {tuple(dy.shape)} does not match descriptor {d.key()}")
@@ -269,7 +270,16 @@ def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None):
     ws, nb = _conv_ws(d, dy.device)
     timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
     t0 = KERNEL_TIMER.begin() if timed else None
-    _lib.call("nsg_conv_dgrad", byref(d), _p(dy), _p(w_dgrad), _p(dx), c_int32(0), _p(ws), c_size_t(nb), _stream())
+    if add is not None or relu_x is not None:
+        for t, nm in ((add, "add"), (relu_x, "relu_x")):
+            if t is not None:
+                _chk(t, nm, dx.dtype)
+                if t.shape != dx.shape:
+                    raise _lib.NsgError(f"conv_dgrad: {nm} shape {tuple(t.shape)} does not match dx {tuple(dx.shape)}")
+        _lib.call("nsg_conv_dgrad_relu_add", byref(d), _p(dy), _p(w_dgrad), _p(add), _p(relu_x), _p(dx), c_int32(0), _p(ws),
+                  c_size_t(nb), _stream())
+    else:
+        _lib.call("nsg_conv_dgrad", byref(d), _p(dy), _p(w_dgrad), _p(dx), c_int32(0), _p(ws), c_size_t(nb), _stream())
     if timed:
         KERNEL_TIMER.end("gather_gemm_f32", t0, _gemm_flops(d))
     return dx

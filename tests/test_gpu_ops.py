@@ -224,6 +224,12 @@ def test_conv_forward_dgrad_wgrad(case):
     dyg = gpu(nhwc(dy))
     dxg = ops.conv_dgrad(d, dyg, wd)
     _close(nchw(dxg.cpu()), gx, what="dgrad")
+    if Ci > 1 and Co > 1:   # (dgrad + skip gradient) * ReLU mask in the dgrad store == the two separate kernels, bit for bit in fp32
+        skip = torch.randn(dxg.shape, generator=g).to(DEV)
+        rx = torch.relu(torch.randn(dxg.shape, generator=g)).to(DEV)
+        fused = ops.conv_dgrad(d, dyg, wd, add=skip, relu_x=rx)
+        assert torch.equal(fused, ops.relu_backward_add(skip, dxg, rx))
+        assert torch.equal(ops.conv_dgrad(d, dyg, wd, relu_x=rx), ops.relu_backward_add(dxg, None, rx))
     dwg, dbg = ops.conv_wgrad(d, xg, dyg, wshape, flags=ops.NSG_RELU_IN if relu_in else 0)
     _close(dwg.cpu(), gw, what="wgrad")
     _close(dbg.cpu(), gb, what="bias grad")
