@@ -36,7 +36,7 @@ namespace {
 constexpr int LDS_PITCH = 36;   // floats per staged row (32 + 4 pad)
 
 template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gather_gemm_kernel(const GatherGemmParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN > 4 ? 1 : 2))) void gather_gemm_kernel(const GatherGemmParams p)
 {
     constexpr int EPV = 16 / (int)sizeof(TI);   // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
     constexpr int KC = 8 * EPV;                 // channels per K-chunk: 128 bytes of a row
@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [2][BM][36]
     float *Bs = smem + 2 * BM * LDS_PITCH;    // [2][BN][36]
-    int *rowoff = reinterpret_cast<int *>(Bs + 2 * BN * LDS_PITCH);  // [BM]
+    // the region serves the operand stages, then the output staging tile (+ the statistics scratch): sized for the larger
+    constexpr int STAGE_FLOATS = 2 * BM * LDS_PITCH + 2 * BN * LDS_PITCH;
+    constexpr int REGION_FLOATS = STAGE_FLOATS > BM * CP + 512 ? STAGE_FLOATS : BM * CP + 512;
+    int *rowoff = reinterpret_cast<int *>(smem + REGION_FLOATS);  // [BM]
     float *Cs = smem;                         // epilogue: [BM][CP], reuses As/Bs
 
     const int tid = threadIdx.x;
@@ -64,8 +67,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int l31 = lane & 31, h = lane >> 5;
 
     const int ntiles_n = (p.CO + BN - 1) / BN;
-    const int mtile = blockIdx.x / ntiles_n;
-    const int ntile = blockIdx.x % ntiles_n;
+    // Blocks are dealt round-robin over the 8 XCDs (observed, speed only): give each XCD a CONTIGUOUS run of tiles so
+    // that the rows a tile shares with its neighbours (the taps' halo) are hits in that XCD's own L2.  Bijective for
+    // any grid size (cdna_hip_programming.md, XCD swizzle).
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    }
+    const int mtile = bid / ntiles_n;
+    const int ntile = bid % ntiles_n;
     const int m0 = mtile * BM;
     const int n0 = ntile * BN;
     const int cls = blockIdx.y;
@@ -117,8 +128,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         wmask[j] = n < p.CO ? 0xffffffffu : 0u;
     }
     // ---- output row offsets ----
-    if (tid < BM) {
-        const int m = m0 + tid;
+    for (int t = tid; t < BM; t += 256) {
+        const int m = m0 + t;
         int off = -1;
         if (m < p.M) {
             const int b = m / (p.RH * p.RW);
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             const int ox = (MODE == 0) ? rx : 2 * rx + px;
             if (oy < p.OH && ox < p.OW) off = ((b * p.OH + oy) * p.OW + ox) * p.CO;  // odd extents: last class row/col absent
         }
-        rowoff[tid] = off;
+        rowoff[t] = off;
     }
 
     const int nchunks = (p.CI + KC - 1) / KC;
@@ -259,9 +270,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         compute(1);
     }
     if (p.stamps && tid == 0) {   // diagnostics: never read by any kernel
-        const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-        p.stamps[2 * bid] = __builtin_amdgcn_s_memtime() - st_t0;
-        p.stamps[2 * bid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        const int sbid = blockIdx.y * gridDim.x + blockIdx.x;
+        p.stamps[2 * sbid] = __builtin_amdgcn_s_memtime() - st_t0;
+        p.stamps[2 * sbid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
     __syncthreads();   // everyone is done reading As/Bs: the region becomes the output staging tile
 
@@ -364,7 +375,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         constexpr int PARTS = 256 / BN;          // threads per column
         constexpr int RPP = BM / PARTS;          // rows per part
         float *red = smem + BM * CP;             // [2][256] scratch behind the staging tile
-        static_assert((size_t)BM * CP + 512 <= (size_t)2 * BM * LDS_PITCH + (size_t)2 * BN * LDS_PITCH, "no room for the stats scratch");
         const int colw = tid % BN, part = tid / BN;
         const bool all_valid = (MODE == 0) ? (m0 + BM <= p.M) : false;   // conv-mode interior tile: every row is real
         const float pivot = Cs[colw];            // row 0 of the tile (always a real row when the tile has any)
@@ -417,8 +427,8 @@ int launch_one(const GatherGemmParams &p, hipStream_t s)
 {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t STAGE_FLOATS = (size_t)2 * BM * LDS_PITCH + (size_t)2 * BN * LDS_PITCH;
-    static_assert((size_t)BM * (BN + 4) <= STAGE_FLOATS, "epilogue tile must fit the staging region");
-    const size_t lds = STAGE_FLOATS * sizeof(float) + BM * sizeof(int);
+    constexpr size_t CS_FLOATS = (size_t)BM * (BN + 4) + 512;
+    const size_t lds = (STAGE_FLOATS > CS_FLOATS ? STAGE_FLOATS : CS_FLOATS) * sizeof(float) + BM * sizeof(int);
     const int ntn = (p.CO + BN - 1) / BN;
     const int64_t ntm = nsg_cdiv(p.M, BM);
     const int64_t gx = ntm * ntn;
@@ -443,15 +453,25 @@ int launch_cfg(const GatherGemmParams &p, hipStream_t s)
     return relu ? launch_one<TI, TO, WM, WN, TM, TN, 1, true>(p, s) : launch_one<TI, TO, WM, WN, TM, TN, 1, false>(p, s);
 }
 
+// 0: always 128-row tiles; 1: 256 x 128 tiles (one workgroup per CU, 128 x 64 per wave) for large bf16 problems
+static int g_gather_big_tile = 0;   // measured on MI355X: the compiler-scheduled 256-row variant runs 480 vs 610 TFLOP/s (exposed LDS latency at one wave per SIMD)
+
 template <typename TI, typename TO>
 int launch_typed(const GatherGemmParams &p, hipStream_t s)
 {
+    if constexpr (sizeof(TI) == 2) {
+        // bf16: a 128 x 128 x 64 chunk is only 512 matrix-pipe cycles per wave while its LDS stores alone cost ~400;
+        // 256 rows per workgroup amortise the weight tile and the barrier over twice the MFMAs
+        if (g_gather_big_tile && p.CO > 64 && p.stats == nullptr && p.M >= 256 * 512) return launch_cfg<TI, TO, 2, 2, 4, 2>(p, s);
+    }
     if (p.CO > 64) return launch_cfg<TI, TO, 2, 2, 2, 2>(p, s);   // 128 x 128
     if (p.CO > 32) return launch_cfg<TI, TO, 2, 2, 2, 1>(p, s);   // 128 x 64
     return launch_cfg<TI, TO, 4, 1, 1, 1>(p, s);                  // 128 x 32
 }
 
 }  // namespace
+
+extern "C" NSG_API void nsg_debug_set_gather_big_tile(int on) { g_gather_big_tile = on; }
 
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 {

@@ -2,10 +2,13 @@
 """Summarise rocprofv3 output into profiles/: per-kernel time from a --kernel-trace --stats run and
 per-kernel HBM traffic from two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024
-(FETCH_SIZE reports half of a wide coalesced read; checked here on relu_bwd_add / bn_apply whose
-byte counts are known).
+(FETCH_SIZE reports half of a wide coalesced read; checked on bn_apply / relu_bwd_add whose byte counts
+are known).
 
-    python scripts/pmc_summary.py <stats_dir> <fetch_dir> <write_dir> <tag> [--steps-in-pmc N]
+    python scripts/pmc_summary.py <stats_dir> <fetch_dir> <write_dir> <tag> <dtype: f32|bf16>
+
+Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_hbm_traffic.csv and updates the <dtype> entry of
+profiles/pmc_traffic_latest.json (what bench.py reports as roofline.traffic).
 """
 import collections
 import csv
@@ -18,24 +21,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").replace("unsigned short", "bf16").split("(")[0]
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[0]
 
 
 def counters(d, cname):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
     agg = collections.OrderedDict()
-    for r in csv.DictReader(open(f)):
+    for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
         if r["Counter_Name"] == cname:
             agg.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
     return agg
 
 
 def main():
-    stats_dir, fetch_dir, write_dir, tag = sys.argv[1:5]
+    stats_dir, fetch_dir, write_dir, tag, dtype = sys.argv[1:6]
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    stats = glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0]
-    rows = list(csv.DictReader(open(stats)))
+    rows = list(csv.DictReader(open(find(stats_dir, "kernel_stats.csv"))))
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
@@ -52,14 +60,22 @@ def main():
             mb = (2 * fe + wr) * 1024 / 1e6
             table[k] = {"launches": len(v), "hbm_bytes_per_launch": (2 * fe + wr) * 1024}
             w.writerow([k, len(v), f"{fe:.1f}", f"{wr:.1f}", f"{mb:.1f}"])
-    # dominant kernel: every gather_gemm_f32 128x128 instantiation, launch-weighted
-    gg = {k: v for k, v in table.items() if k.startswith("gather_gemm_f32<2, 2, 2, 2")}
+    # dominant kernel: the 128x128 gather_gemm instantiations of this dtype (the launches bench.py times), launch-weighted
+    el = "bf16, bf16" if dtype == "bf16" else "float, float"
+    gg = {k: v for k, v in table.items() if k.startswith(f"gather_gemm_kernel<{el}, 2, 2, 2, 2")}
     n = sum(v["launches"] for v in gg.values())
     avg = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in gg.values()) / max(1, n)
-    json.dump({"tag": tag, "kernel": "gather_gemm_f32", "launches": n, "hbm_bytes_per_launch": avg,
-               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py; bytes=(2*FETCH_SIZE+WRITE_SIZE)*1024"},
-              open(os.path.join(out_dir, "pmc_traffic_latest.json"), "w"), indent=1)
-    print("gather_gemm_f32: %.1f MB HBM traffic per launch over %d launches" % (avg / 1e6, n))
+    latest = os.path.join(out_dir, "pmc_traffic_latest.json")
+    cur = {}
+    if os.path.exists(latest):
+        cur = json.load(open(latest))
+        if "hbm_bytes_per_launch" in cur:      # old single-entry layout
+            cur = {}
+    cur[dtype] = {"tag": tag, "kernel": f"gather_gemm_kernel<{el}, 128x128>", "launches": n, "hbm_bytes_per_launch": avg,
+                  "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py --dtype %s; "
+                          "bytes=(2*FETCH_SIZE+WRITE_SIZE)*1024" % dtype}
+    json.dump(cur, open(latest, "w"), indent=1)
+    print("gather_gemm (%s): %.1f MB HBM traffic per launch over %d launches" % (dtype, avg / 1e6, n))
 
 
 if __name__ == "__main__":
