@@ -92,6 +92,8 @@ def main():
             print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an AMD GPU: the HIP path has no CPU fallback")
+    if "NSG_DEVICE_INDEX" in os.environ:       # rehearsal knob: several ranks on one GPU (with NSG_DIST_BACKEND=gloo)
+        local = int(os.environ["NSG_DEVICE_INDEX"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     D, K, T, B = args.dim, args.z_dim, args.frames, args.batch
