@@ -98,6 +98,15 @@ NSG_API size_t nsg_vq_workspace_bytes(int64_t N, int32_t D, int32_t K);
 NSG_API int nsg_vq_forward(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
                            float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same search for the bf16 compute mode: the contraction runs on the bf16 matrix pipe with both fp32 operands
+ * split into bf16 hi + lo parts (3 MFMAs per 16 channels, fp32 accumulate): distances carry a relative error of
+ * ~2^-16, so on near-ties the chosen code may differ from the reference's (NOT the bit-exact search; the fp32
+ * parity mode uses nsg_vq_forward).  D % 8 == 0.  Workspace: nsg_vq_bf16x3_workspace_bytes. */
+NSG_API size_t nsg_vq_bf16x3_workspace_bytes(int64_t N, int32_t D, int32_t K);
+NSG_API int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+                                  float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 /* out[r] = torch.sum(v[r]**2) with ATen's CPU summation order (vector_quantization.py:12-13). */
 NSG_API int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream);
 

@@ -57,6 +57,7 @@ class VQEmbedding(nn.Module):
         self.embedding.weight.data.uniform_(-1. / z_dim, 1. / z_dim)
         self.ema_decay = ema_decay
         self.ema_eps = ema_eps
+        self.search_impl = "mfma"     # "bf16x3" in the bf16 compute mode (set by VQVAE)
         if ema_decay is not None:
             self.embedding.weight.requires_grad_(False)
             self.register_buffer("ema_count", torch.zeros(z_dim))
@@ -64,11 +65,11 @@ class VQEmbedding(nn.Module):
 
     def forward(self, z_e_x):
         z_e_x_ = Fn.to_nhwc(z_e_x)
-        return vq(z_e_x_, self.embedding.weight)
+        return vq(z_e_x_, self.embedding.weight, self.search_impl)
 
     def straight_through(self, z_e_x):
         z_e_x_ = Fn.to_nhwc(z_e_x)
-        z_q_x_, indices = vq_st(z_e_x_, self.embedding.weight.detach())
+        z_q_x_, indices = vq_st(z_e_x_, self.embedding.weight.detach(), self.search_impl)
         z_q_x = Fn.to_nchw_view(z_q_x_)
         z_q_x_bar_ = codebook_lookup(self.embedding.weight, indices).view_as(z_e_x_)
         z_q_x_bar = Fn.to_nchw_view(z_q_x_bar_)
@@ -147,6 +148,10 @@ class VQVAE(nn.Module):
         )
         self.encoder.compute_dtype = compute_dtype
         self.decoder.compute_dtype = compute_dtype
+        if compute_dtype == torch.bfloat16:
+            # the quantiser's search on the bf16 matrix pipe with split fp32 operands (distances to ~2^-16; the
+            # fp32 parity mode keeps the bit-exact search)
+            self.codebook.search_impl = "bf16x3"
         self.n_speakers = n_speakers
         if n_speakers is not None:
             self.speaker_embedding = nn.Embedding(n_speakers, dim)

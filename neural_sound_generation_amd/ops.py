@@ -107,7 +107,9 @@ def _gemm_flops(d: "ConvDesc") -> float:
 # vector quantiser
 # ------------------------------------------------------------------------------------------------
 def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma"):
-    """x2d (N,D), codebook (K,D) -> idx (N,) int64 [, codes (N,D)] [, dmin (N,)]"""
+    """x2d (N,D), codebook (K,D) -> idx (N,) int64 [, codes (N,D)] [, dmin (N,)]
+    impl: "mfma" = the bit-exact fp32 search (parity mode); "valu" = its vector-ALU cross-check; "bf16x3" = the bf16
+    mode's search on the bf16 matrix pipe with split operands (relative distance error ~2^-16: near-ties may differ)."""
     _chk(x2d, "x"); _chk(codebook, "codebook")
     N, D = x2d.shape
     K, D2 = codebook.shape
@@ -117,9 +119,10 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma"):
     codes = torch.empty_like(x2d) if want_codes else None
     dmin = torch.empty(N, dtype=torch.float32, device=x2d.device) if want_dist else None
     if N > 0:
-        nb = _lib.query("nsg_vq_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
+        wsfn = "nsg_vq_bf16x3_workspace_bytes" if impl == "bf16x3" else "nsg_vq_workspace_bytes"
+        nb = _lib.query(wsfn, c_int64(N), c_int32(D), c_int32(K))
         ws = WS.get(nb, x2d.device)
-        fn = "nsg_vq_forward" if impl == "mfma" else "nsg_debug_vq_forward_valu"
+        fn = {"mfma": "nsg_vq_forward", "valu": "nsg_debug_vq_forward_valu", "bf16x3": "nsg_vq_forward_bf16x3"}[impl]
         _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin),
                   _p(ws), c_size_t(nb), _stream())
     return idx, codes, dmin

@@ -61,7 +61,8 @@ class FusedTrainStep:
         ze, es = engine.encoder_forward(x, self.encP, True, dtype=self.dtype, packs=enc_packs)
         D = ze.shape[-1]
         K = self.codebook.shape[0]
-        idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True)
+        idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True,
+                                    impl=getattr(self.model.codebook, "search_impl", "mfma"))
         zq = zq.view_as(ze)
         zdec = zq
         if self.spk is not None and g is not None:

@@ -7,7 +7,8 @@ Same names, argument meaning and error behaviour as the reference (vector_quanti
 differentiating through plain `vq` raises RuntimeError (:26-30); `vq_st` passes the output gradient
 straight to the inputs (:52) and scatter-adds it into the codebook gradient when the codebook
 requires grad (:53-61).  The search itself is nsg_vq_forward: distances are never materialised and
-the indices are bit-identical to the reference's CPU result.
+the indices are bit-identical to the reference's CPU result.  The optional third argument
+`impl` ("mfma" by default) lets the bf16 compute mode select its own search ("bf16x3", nsg_vq_forward_bf16x3).
 """
 from __future__ import annotations
 
@@ -19,11 +20,11 @@ from . import ops
 
 class VectorQuantization(Function):
     @staticmethod
-    def forward(ctx, inputs, codebook):
+    def forward(ctx, inputs, codebook, impl="mfma"):
         with torch.no_grad():
             embedding_size = codebook.size(1)
             flat = inputs.detach().contiguous().view(-1, embedding_size)
-            idx, _, _ = ops.vq_forward(flat, codebook.detach().contiguous(), want_codes=False)
+            idx, _, _ = ops.vq_forward(flat, codebook.detach().contiguous(), want_codes=False, impl=impl)
             indices = idx.view(*inputs.shape[:-1])
             ctx.mark_non_differentiable(indices)
             return indices
@@ -38,11 +39,11 @@ class VectorQuantization(Function):
 
 class VectorQuantizationStraightThrough(Function):
     @staticmethod
-    def forward(ctx, inputs, codebook):
+    def forward(ctx, inputs, codebook, impl="mfma"):
         embedding_size = codebook.size(1)
         flat = inputs.detach().contiguous().view(-1, embedding_size)
         cb = codebook.detach().contiguous()
-        indices_flatten, codes_flatten, _ = ops.vq_forward(flat, cb, want_codes=True)  # search + gather fused
+        indices_flatten, codes_flatten, _ = ops.vq_forward(flat, cb, want_codes=True, impl=impl)  # search + gather fused
         ctx.save_for_backward(indices_flatten)
         ctx.codebook_rows = cb.size(0)
         ctx.mark_non_differentiable(indices_flatten)
@@ -57,7 +58,7 @@ class VectorQuantizationStraightThrough(Function):
             (indices,) = ctx.saved_tensors
             g = grad_output.contiguous().view(indices.numel(), -1)
             grad_codebook = ops.index_add_rows(indices, g, ctx.codebook_rows)
-        return grad_inputs, grad_codebook
+        return grad_inputs, grad_codebook, None
 
 
 class CodebookLookup(Function):
@@ -93,8 +94,14 @@ class AddPerClip(Function):
         return gz, gr
 
 
-vq = VectorQuantization.apply
+def vq(inputs, codebook, impl="mfma"):
+    return VectorQuantization.apply(inputs, codebook, impl)
+
+
+def vq_st(inputs, codebook, impl="mfma"):
+    return VectorQuantizationStraightThrough.apply(inputs, codebook, impl)
+
+
 add_per_clip = AddPerClip.apply
-vq_st = VectorQuantizationStraightThrough.apply
 codebook_lookup = CodebookLookup.apply
 __all__ = ["vq", "vq_st", "codebook_lookup"]

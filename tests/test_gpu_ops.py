@@ -108,6 +108,28 @@ def test_vq_full_size_properties():
     assert np.array_equal(dmin.cpu().numpy()[sel], wdist)
 
 
+@pytest.mark.parametrize("N,D,K", [(640, 64, 128), (1000, 128, 512), (333, 24, 40), (256, 256, 1000), (129, 8, 7)])
+def test_vq_bf16x3_search_is_near_exact(golden_dir, N, D, K):
+    """The bf16 mode's search (split operands on the bf16 pipe): not bit-exact by design -- the code it picks must be
+    a true nearest code up to its stated distance error (~2^-16 relative), and on well-separated data the very same."""
+    g = torch.Generator().manual_seed(N + D + K)
+    x = torch.randn(N, D, generator=g)
+    e = torch.randn(K, D, generator=g)
+    idx, codes, dmin = ops.vq_forward(gpu(x), gpu(e), want_dist=True, impl="bf16x3")
+    idx = idx.cpu()
+    d = torch.cdist(x.double(), e.double()) ** 2
+    true_min, true_idx = d.min(dim=1)
+    picked = d[torch.arange(N), idx]
+    scale = (x.double().norm(dim=1) ** 2 + (e.double().norm(dim=1) ** 2).max())
+    assert float(((picked - true_min) / scale).max()) <= 1e-4          # a nearest code within the error bound
+    assert float((idx == true_idx).float().mean()) >= 0.99              # separated data: the same code
+    assert torch.equal(codes.cpu(), e[idx])                             # gathered rows are the fp32 codebook rows
+    assert float(((dmin.cpu().double() - picked) / scale).abs().max()) <= 1e-4
+    f = golden(golden_dir, "vq_ops.npz")                                # the robust fixture: identical indices
+    i1, _, _ = ops.vq_forward(gpu(torch.from_numpy(f["f1.x"])), gpu(torch.from_numpy(f["f1.e"])), impl="bf16x3")
+    assert np.array_equal(i1.cpu().numpy(), f["f1.idx"])
+
+
 def test_vq_operator_surface(golden_dir):
     g = golden(golden_dir, "vq_ops.npz")
     x = gpu(torch.from_numpy(g["st.x"])).requires_grad_(True)
