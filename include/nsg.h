@@ -121,6 +121,12 @@ NSG_API size_t nsg_index_add_workspace_bytes(int64_t N, int32_t D, int32_t K);
 NSG_API int nsg_index_add_rows(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
                                float *counts_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same for the bf16 compute mode: the one-hot reduction runs on the bf16 matrix pipe with g split into bf16
+ * hi + lo parts (relative error of a sum ~2^-17; deterministic).  Falls back to nsg_index_add_rows's kernel when
+ * D is not a multiple of 8 or D <= 32.  Same workspace. */
+NSG_API int nsg_index_add_rows_bf16x2(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
+                                      float *counts_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* out[i][:] = e[idx[i]][:] for i < N.  Replaces torch.index_select(codebook, 0, indices)
  * (vector_quantization.py:40-41, src/models.py:137) and self.codebook.embedding(latents)
  * (src/models.py:194).  Indices outside [0,K) are clamped. */

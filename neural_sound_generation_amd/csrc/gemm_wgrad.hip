@@ -466,6 +466,181 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// index_add_ for the bf16 compute mode: dst[k][c] = sum over pixels with idx[pix] == k of g[pix][c]  (g fp32), as the
+// same pixel-reduction GEMM with a generated one-hot P operand (exact in bf16) and g split into bf16 hi + lo parts
+// (g = hi + lo + O(2^-17 |g|)): two v_mfma_f32_32x32x16_bf16 per k-step instead of eight fp32 MFMAs.  Deterministic
+// (fixed slab order) like every other reduction here; relative error of a sum ~2^-17, far below bf16 storage.
+// ------------------------------------------------------------------------------------------------
+constexpr int KPO = 32;   // pixels per chunk (LDS: 3 tiles x 2 buffers must leave room for two workgroups per CU)
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void onehot_gemm_bf16x2(const WgradParams p)
+{
+    constexpr int TA = WM * TM * 32;
+    constexpr int TC = WN * TN * 32;
+    constexpr int PP = TA + 32, QP = TC + 32;            // LDS row pitches in bf16 elements
+    constexpr int PA8 = TA / 8, QC8 = TC / 8;
+    constexpr int PJ = KPO * PA8 / 256, QJ = KPO * QC8 / 256;
+    static_assert(KPO * PA8 % 256 == 0 && KPO * QC8 % 256 == 0, "every thread stages the same number of pieces");
+    const float *__restrict__ gQ = reinterpret_cast<const float *>(p.Q);
+    const int64_t *__restrict__ gidx = p.idx;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gQ), 0, (int)p.q_bytes, 0x00020000);
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bf16_t *Ps = reinterpret_cast<bf16_t *>(smem);       // [2][KPO][PP]
+    bf16_t *Qh = Ps + 2 * KPO * PP;                      // [2][KPO][QP]
+    bf16_t *Ql = Qh + 2 * KPO * QP;                      // [2][KPO][QP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int h = lane >> 5;
+    const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+
+    const int slab = blockIdx.x;
+    const int ctiles = (p.C + TC - 1) / TC;
+    const int a0 = (blockIdx.z / ctiles) * TA;
+    const int c0 = (blockIdx.z % ctiles) * TC;
+    const int mbeg = slab * p.slab_rows;
+    const int mend = min(p.Mp, mbeg + p.slab_rows);
+    const int nchunk = (mend - mbeg + KPO - 1) / KPO;
+
+    constexpr int PSTEP = 256 / PA8, QSTEP = 256 / QC8;
+    const int ppix = tid / PA8, pa8 = (tid % PA8) * 8;
+    const int qpix = tid / QC8, qc8 = (tid % QC8) * 8;
+    const bool qc_ok = (c0 + qc8) < p.C;                 // C % 8 == 0: a piece is inside or outside as a whole
+
+    int ri0[PJ], ri1[PJ];                                // code of each staged pixel (two register stages)
+    v4f rq0[2 * QJ], rq1[2 * QJ];
+    int g_mb = mbeg;
+    auto gload = [&](int (&ri)[PJ], v4f (&rq)[2 * QJ]) {
+        const int mb = g_mb;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const int m = mb + ppix + PSTEP * j;
+            const int64_t code = gidx[m < mend ? m : mbeg];      // clamped, unconditional
+            ri[j] = m < mend ? (int)code : -0x40000000;          // a pixel past the slab matches no code
+        }
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const int m = mb + qpix + QSTEP * j;
+            const bool ok = qc_ok & (m < mend);
+            const unsigned off = ok ? (unsigned)(m * p.C + c0 + qc8) * 4u : OOB;
+            rq[2 * j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_q, (int)off, 0, 0));
+            rq[2 * j + 1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_q, (int)(ok ? off + 16u : OOB), 0, 0));
+        }
+        g_mb += KPO;
+    };
+    auto lstore = [&](int buf, const int (&ri)[PJ], const v4f (&rq)[2 * QJ]) {
+        bf16_t *ps = Ps + buf * KPO * PP;
+        bf16_t *qh = Qh + buf * KPO * QP;
+        bf16_t *ql = Ql + buf * KPO * QP;
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const unsigned k = (unsigned)(ri[j] - (a0 + pa8));   // < 8 exactly when the pixel's code is one of this piece's 8
+            const unsigned one = k < 8u ? (0x3f80u << (16 * (k & 1u))) : 0u;   // bf16 1.0 in the element's half of its dword
+            const unsigned w = k >> 1;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const v4u v = {w == 0 ? one : 0u, w == 1 ? one : 0u, w == 2 ? one : 0u, w == 3 ? one : 0u};
+            *reinterpret_cast<v4u *>(ps + (ppix + PSTEP * j) * PP + pa8) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < QJ; ++j) {
+            const float v[8] = {rq[2 * j].x, rq[2 * j].y, rq[2 * j].z, rq[2 * j].w, rq[2 * j + 1].x, rq[2 * j + 1].y, rq[2 * j + 1].z, rq[2 * j + 1].w};
+            s16x8 hv, lv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bf16_t hb = nsg_f2bf(v[e]);
+                hv[e] = (short)hb;
+                lv[e] = (short)nsg_f2bf(v[e] - nsg_bf2f(hb));
+            }
+            *reinterpret_cast<s16x8 *>(qh + (qpix + QSTEP * j) * QP + qc8) = hv;
+            *reinterpret_cast<s16x8 *>(ql + (qpix + QSTEP * j) * QP + qc8) = lv;
+        }
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int cur) {
+        const bf16_t *pbase = Ps + cur * KPO * PP + (8 * h + q) * PP + wr * TM * 32 + 16 * g16 + 4 * pp;
+        const bf16_t *hbase = Qh + cur * KPO * QP + (8 * h + q) * QP + wc * TN * 32 + 16 * g16 + 4 * pp;
+        const bf16_t *lbase = Ql + cur * KPO * QP + (8 * h + q) * QP + wc * TN * 32 + 16 * g16 + 4 * pp;
+#pragma unroll
+        for (int ks = 0; ks < KPO / 16; ++ks) {
+            s16x8 a[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const s16x4 lo = lds_tr_read(pbase + (16 * ks) * PP + i * 32);
+                const s16x4 hi = lds_tr_read(pbase + (16 * ks + 4) * PP + i * 32);
+                a[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const s16x4 lo = lds_tr_read(hbase + (16 * ks) * QP + j * 32);
+                const s16x4 hi = lds_tr_read(hbase + (16 * ks + 4) * QP + j * 32);
+                bh[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const s16x4 lo2 = lds_tr_read(lbase + (16 * ks) * QP + j * 32);
+                const s16x4 hi2 = lds_tr_read(lbase + (16 * ks + 4) * QP + j * 32);
+                bl[j] = s16x8{lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    if (nchunk > 0) {
+        gload(ri0, rq0);
+        if (nchunk > 1) gload(ri1, rq1);
+        lstore(0, ri0, rq0);
+        __syncthreads();
+        int ch = 0;
+        for (; ch + 2 < nchunk; ch += 2) {
+            gload(ri0, rq0);
+            compute(0);
+            lstore(1, ri1, rq1);
+            __syncthreads();
+            gload(ri1, rq1);
+            compute(1);
+            lstore(0, ri0, rq0);
+            __syncthreads();
+        }
+        compute(0);
+        if (ch + 1 < nchunk) {
+            lstore(1, ri1, rq1);
+            __syncthreads();
+            compute(1);
+        }
+    }
+
+    const int l31 = lane & 31;
+    float *dst = p.partial + ((size_t)slab * p.A) * p.C;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + wc * TN * 32 + j * 32 + l31;
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int a = a0 + wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (a < p.A) dst[(size_t)a * p.C + c] = acc[i][j][r];
+            }
+    }
+}
+
 // dst[(a*C + c)*ntaps + t] = sum_slab partial[slab][t][a][c]
 // One thread per output when there are few slabs; otherwise 8 lanes per output split the slabs and
 // the partial sums are added in lane order (fixed order either way: bitwise reproducible).
@@ -578,8 +753,21 @@ int launch_wg_diag(const WgradParams &p, int nslab, hipStream_t s)
 }
 
 template <int WM, int WN, int TM, int TN>
+int launch_onehot_bf16x2(const WgradParams &p, int nslab, hipStream_t s)
+{
+    constexpr int TA = WM * TM * 32, TC = WN * TN * 32;
+    const size_t lds = (size_t)2 * KPO * ((TA + 32) + 2 * (TC + 32)) * sizeof(bf16_t);
+    dim3 grid(nslab, 1, (unsigned)(nsg_cdiv(p.A, TA) * nsg_cdiv(p.C, TC)));
+    hipLaunchKernelGGL((onehot_gemm_bf16x2<WM, WN, TM, TN>), grid, dim3(256), lds, s, p);
+    return nsg_check_launch("onehot_gemm_bf16x2");
+}
+
+template <int WM, int WN, int TM, int TN>
 int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
 {
+    if constexpr (WN * TN * 32 >= 64) {
+        if (p.onehot == 2) return launch_onehot_bf16x2<WM, WN, TM, TN>(p, nslab, s);   // one-hot on the bf16 pipe, split rows
+    }
     if (p.onehot) return launch_wg1<float, WM, WN, TM, TN, true>(p, nslab, s);   // one-hot: Q (the scattered rows) is fp32
     if (p.dtype == NSG_BF16) return g_wgrad_bf16_native ? launch_wg_bf16<WM, WN, TM, TN>(p, nslab, s) : launch_wg1<bf16_t, WM, WN, TM, TN, false>(p, nslab, s);
     return launch_wg1<float, WM, WN, TM, TN, false>(p, nslab, s);
@@ -608,6 +796,12 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     p.slab_rows = sp.slab_rows;
     p.stamps = g_wgrad_stamps;
     p.stagger = g_wgrad_stagger;
+    if (p.onehot == 2) {
+        const uint64_t qb = (uint64_t)p.Mp * p.C * 4;
+        if (qb >= 0xfffffff0ull) return nsg_fail(NSG_E_UNSUPPORTED, "index_add (bf16 pipe): operand larger than 4 GiB");
+        if (p.C % 8 != 0) return nsg_fail(NSG_E_UNSUPPORTED, "index_add (bf16 pipe): D=%d must be a multiple of 8", p.C);
+        p.q_bytes = (unsigned)qb;
+    }
     if (!p.onehot && p.dtype == NSG_BF16) {   // 32-bit byte offsets in the bf16 kernel's buffer loads
         const uint64_t pb = (uint64_t)p.Mp * p.A * 2, qb = (uint64_t)p.B * p.QH * p.QW * p.C * 2;
         if (pb >= 0xfffffff0ull || qb >= 0xfffffff0ull) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: operand larger than 4 GiB: split the batch");

@@ -437,8 +437,24 @@ size_t nsg_index_add_workspace_bytes(int64_t N, int32_t D, int32_t K)
     return nsg_align_up((size_t)K * sizeof(int), 256) + nsg_wgrad_workspace_bytes(N, 1, K, D);
 }
 
+static int index_add_impl(int onehot_mode, const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
+                          float *counts_out, void *workspace, size_t workspace_bytes, void *stream);
+
 int nsg_index_add_rows(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out, float *counts_out,
                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    return index_add_impl(1, idx, g, N, D, K, out, counts_out, workspace, workspace_bytes, stream);
+}
+
+int nsg_index_add_rows_bf16x2(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out, float *counts_out,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    // rows narrower than 64 channels / not a multiple of 8 go through the fp32 kernel (same results up to rounding)
+    return index_add_impl((D % 8 == 0 && D > 32) ? 2 : 1, idx, g, N, D, K, out, counts_out, workspace, workspace_bytes, stream);
+}
+
+static int index_add_impl(int onehot_mode, const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
+                          float *counts_out, void *workspace, size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(idx && g && out && N > 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_index_add_rows: bad argument");
     NSG_REQUIRE(N < 0x7fffffff, NSG_E_UNSUPPORTED, "nsg_index_add_rows: too many rows");
@@ -465,7 +481,7 @@ int nsg_index_add_rows(const int64_t *idx, const float *g, int64_t N, int32_t D,
     p.QH = 1; p.QW = (int)N; p.C = D;
     p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.Mp = (int)N;
-    p.onehot = 1;
+    p.onehot = onehot_mode;
     return nsg_launch_wgrad(p, out, reinterpret_cast<char *>(workspace) + cnt_bytes, workspace_bytes - cnt_bytes, s);
 }
 

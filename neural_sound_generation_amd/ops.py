@@ -135,16 +135,17 @@ def rowsumsq(v):
     return out
 
 
-def index_add_rows(idx, g2d, K, want_counts=False):
-    """out[k] = sum of rows of g2d whose idx == k; deterministic."""
+def index_add_rows(idx, g2d, K, want_counts=False, impl="f32"):
+    """out[k] = sum of rows of g2d whose idx == k; deterministic.  impl: "f32" (fp32 matrix pipe, exact products) or
+    "bf16x2" (the bf16 compute mode: rows split into bf16 hi + lo, relative error of a sum ~2^-17)."""
     _chk(idx, "idx", torch.int64); _chk(g2d, "g")
     N, D = g2d.shape
     out = torch.empty(K, D, dtype=torch.float32, device=g2d.device)
     counts = torch.empty(K, dtype=torch.float32, device=g2d.device) if want_counts else None
     nb = _lib.query("nsg_index_add_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
     ws = WS.get(nb, g2d.device)
-    _lib.call("nsg_index_add_rows", _p(idx), _p(g2d), c_int64(N), c_int32(D), c_int32(K), _p(out), _p(counts), _p(ws),
-              c_size_t(nb), _stream())
+    _lib.call("nsg_index_add_rows_bf16x2" if impl == "bf16x2" else "nsg_index_add_rows", _p(idx), _p(g2d), c_int64(N), c_int32(D),
+              c_int32(K), _p(out), _p(counts), _p(ws), c_size_t(nb), _stream())
     return (out, counts) if want_counts else out
 
 

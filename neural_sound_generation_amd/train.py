@@ -34,6 +34,8 @@ class FusedTrainStep:
             nsg_dist.broadcast_flat(self.opt.flat_param, 0, process_group)
         self.dtype = getattr(model, "compute_dtype", torch.float32)
         self.ema = getattr(model.codebook, "ema_decay", None) is not None
+        # bf16 mode: the codebook scatter-add on the bf16 matrix pipe (rows split hi + lo); fp32 mode: exact products
+        self.scatter_impl = "bf16x2" if self.dtype == torch.bfloat16 else "f32"
         self.encP = engine.encoder_params(model.encoder)
         self.decP = engine.decoder_params(model.decoder)
         self.codebook = model.codebook.embedding.weight
@@ -84,7 +86,7 @@ class FusedTrainStep:
             # EMA codebook (extension): no codebook gradient; per-code counts and sums of the assigned
             # encoder rows are the statistics every rank contributes (summed over ranks in step())
             loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False, grad_dtype=self.dtype)
-            s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True)
+            s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
             self.ema_stats = torch.cat([n, s.view(-1)])       # ONE buffer -> ONE small all-reduce
         else:
             loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, grad_dtype=self.dtype)
@@ -94,7 +96,7 @@ class FusedTrainStep:
         return loss_recons, loss_vq, loss_vq
 
     def _codebook_grad(self, idx, dq, K):
-        g = ops.index_add_rows(idx, dq, K)
+        g = ops.index_add_rows(idx, dq, K, impl=self.scatter_impl)
         ops.add(g, None, out=self.g_code)
 
     @torch.no_grad()

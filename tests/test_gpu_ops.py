@@ -130,6 +130,21 @@ def test_vq_bf16x3_search_is_near_exact(golden_dir, N, D, K):
     assert np.array_equal(i1.cpu().numpy(), f["f1.idx"])
 
 
+@pytest.mark.parametrize("N,D,K", [(5000, 128, 512), (777, 64, 100), (4096, 256, 37), (300, 24, 16)])
+def test_index_add_rows_bf16x2(N, D, K):
+    """Codebook scatter-add of the bf16 mode: rows split into bf16 hi + lo on the bf16 pipe; sums to ~2^-17, deterministic."""
+    g = torch.Generator().manual_seed(N + K)
+    idx = torch.randint(0, K, (N,), generator=g)
+    rows = torch.randn(N, D, generator=g)
+    want = torch.zeros(K, D, dtype=torch.float64).index_add_(0, idx, rows.double())
+    got, cnt = ops.index_add_rows(gpu(idx), gpu(rows), K, want_counts=True, impl="bf16x2")
+    scale = torch.zeros(K, D, dtype=torch.float64).index_add_(0, idx, rows.double().abs()).clamp_min(1e-6)
+    assert float(((got.cpu().double() - want).abs() / scale).max()) <= 3e-5
+    assert torch.equal(cnt.cpu(), torch.bincount(idx, minlength=K).float())
+    got2 = ops.index_add_rows(gpu(idx), gpu(rows), K, impl="bf16x2")
+    assert torch.equal(got, got2), "must be bitwise reproducible"
+
+
 def test_vq_operator_surface(golden_dir):
     g = golden(golden_dir, "vq_ops.npz")
     x = gpu(torch.from_numpy(g["st.x"])).requires_grad_(True)
