@@ -36,7 +36,7 @@ namespace {
 constexpr int LDS_PITCH = 36;   // floats per staged row (32 + 4 pad)
 
 template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN > 4 ? 1 : 2))) void gather_gemm_kernel(const GatherGemmParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gather_gemm_kernel(const GatherGemmParams p)
 {
     constexpr int EPV = 16 / (int)sizeof(TI);   // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
     constexpr int KC = 8 * EPV;                 // channels per K-chunk: 128 bytes of a row
@@ -453,25 +453,20 @@ int launch_cfg(const GatherGemmParams &p, hipStream_t s)
     return relu ? launch_one<TI, TO, WM, WN, TM, TN, 1, true>(p, s) : launch_one<TI, TO, WM, WN, TM, TN, 1, false>(p, s);
 }
 
-// 0: always 128-row tiles; 1: 256 x 128 tiles (one workgroup per CU, 128 x 64 per wave) for large bf16 problems
-static int g_gather_big_tile = 0;   // measured on MI355X: the compiler-scheduled 256-row variant runs 480 vs 610 TFLOP/s (exposed LDS latency at one wave per SIMD)
-
 template <typename TI, typename TO>
 int launch_typed(const GatherGemmParams &p, hipStream_t s)
 {
-    if constexpr (sizeof(TI) == 2) {
-        // bf16: a 128 x 128 x 64 chunk is only 512 matrix-pipe cycles per wave while its LDS stores alone cost ~400;
-        // 256 rows per workgroup amortise the weight tile and the barrier over twice the MFMAs
-        if (g_gather_big_tile && p.CO > 64 && p.stats == nullptr && p.M >= 256 * 512) return launch_cfg<TI, TO, 2, 2, 4, 2>(p, s);
-    }
+    // (A 256 x 128 tile -- 128 x 64 per wave, one workgroup per CU -- was built and measured: 480-570 vs 600-640 TFLOP/s on
+    // random bf16 data, with or without sched_group_barrier-pinned fragment prefetch.  Per 128x128x64 chunk the LDS
+    // array is busy ~100 % of the MFMA time already (32 ds_write_b128 at 13 cycles + 64 ds_read_b128 at 4 per
+    // workgroup, two workgroups per CU), so the kernel is LDS-fed-bound; the bigger tile trims that by a quarter but
+    // loses the second wave per SIMD that hides the read latency.  See DESIGN.md 3.1b.)
     if (p.CO > 64) return launch_cfg<TI, TO, 2, 2, 2, 2>(p, s);   // 128 x 128
     if (p.CO > 32) return launch_cfg<TI, TO, 2, 2, 2, 1>(p, s);   // 128 x 64
     return launch_cfg<TI, TO, 4, 1, 1, 1>(p, s);                  // 128 x 32
 }
 
 }  // namespace
-
-extern "C" NSG_API void nsg_debug_set_gather_big_tile(int on) { g_gather_big_tile = on; }
 
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 {
