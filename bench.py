@@ -7,7 +7,7 @@
 
 One "step" = one full training step (forward, three losses, backward, [all-reduce], Adam) of
 VQVAE(1, D=128, K=512) (BASELINE.json configs[1], the reference's `--dim 128 --z-dim 512`, bf16) on a
-synthetic batch of B clips of 80-mel x 1024 frames per GPU, inputs resident in HBM before the timed
+synthetic batch of B = 128 clips of 80-mel x 1024 frames per GPU, inputs resident in HBM before the timed
 region.  Weak scaling: B per GPU is fixed, rank r draws its own clips.  Prints ONE JSON line: the bf16
 mode is `value` (configs[1] is quoted in bf16), the fp32 parity mode is timed in the same run (other_mode).
 """
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="clips per GPU (SURVEY.md 8d: best of {32, 64, 128} for configs[1])")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--z-dim", type=int, default=512)
     ap.add_argument("--frames", type=int, default=1024)
@@ -151,7 +151,7 @@ def main():
         if s is not None:
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-            if os.path.exists(pmc) and (D, K, B, T) == (128, 512, 64, 1024):
+            if os.path.exists(pmc) and (D, K, B, T) == (128, 512, 128, 1024):
                 # HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes of this
                 # command (scripts/profile_round.sh + scripts/pmc_summary.py; PMC cannot be sampled inside the timed run)
                 ent = json.load(open(pmc)).get(args.dtype)
