@@ -56,6 +56,46 @@ class FlatAdam(torch.optim.Optimizer):
         index = {id(p): i for i, p in enumerate(self._params)}
         return [self.grad_views[index[id(t)]] for t in tensors]
 
+    # ---- checkpoint interchange (src/main.py:216-220 saves optimizer.state_dict()) -------------------
+    # Same layout as torch.optim.Adam's: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]},
+    # so a checkpoint written with either optimiser loads into the other.
+    def state_dict(self):
+        g = self.param_groups[0]
+        defaults = dict(torch.optim.Adam([torch.zeros(1)]).defaults)   # every key torch's Adam expects in a group
+        group = {**defaults, "lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "params": list(range(len(self._params)))}
+        state = {}
+        if self.step_count > 0:
+            for i, (p, off) in enumerate(zip(self._params, self.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+        return {"state": state, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self._params):
+            raise ValueError("FlatAdam.load_state_dict: expected one parameter group with %d parameters" % len(self._params))
+        g = self.param_groups[0]
+        g["lr"], g["betas"], g["eps"] = groups[0]["lr"], tuple(groups[0]["betas"]), groups[0]["eps"]
+        if groups[0].get("weight_decay", 0) or groups[0].get("amsgrad", False):
+            raise ValueError("FlatAdam.load_state_dict: weight decay / amsgrad are not implemented")
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, (p, off) in enumerate(zip(self._params, self.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam.load_state_dict: parameters carry different step counts")
+        self.step_count = steps.pop() if steps else 0
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = closure() if closure is not None else None

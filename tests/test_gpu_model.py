@@ -419,3 +419,106 @@ def test_bf16_mode_against_fp32_oracle(dim, z_dim, B, T):
         lr_, lv, _ = step.step(c.to(DEV))
         first = first if first is not None else lr_.item()
     assert lr_.item() < 0.8 * first
+
+
+# ---------------------------------------------------------------------------------------------
+# the steps either side of training: evaluation loss, export, checkpoints, the disk loader
+# ---------------------------------------------------------------------------------------------
+def test_eval_losses_and_test_vqvae_match_the_oracle(golden_dir):
+    from neural_sound_generation_amd import evaluate as E
+    g = golden(golden_dir, "model_tiny.npz")
+    model = build(g)
+    st = {k[len("sd0."):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd0.")}
+    gen = torch.Generator().manual_seed(7)
+    batches = [torch.rand(2, 80, 64, generator=gen), torch.rand(2, 80, 31, generator=gen)]     # (B, 80, T): T=31 pads
+    want_r, want_v = 0.0, 0.0
+    for c in batches:
+        xt, ze, zq, _, _ = O.forward(st, c.unsqueeze(1), training=False)
+        lr_, lv_, _ = O.loss_terms(c.unsqueeze(1), xt, ze, zq)
+        want_r += lr_.item() / len(batches)
+        want_v += lv_.item() / len(batches)
+    loader = [(None, None, c, None, None) for c in batches]
+
+    class A:
+        dataset = "ljspeech"
+    got_r, got_v = E.test_vqvae(A(), model, loader, DEV, 0)
+    assert not model.training
+    assert rel(got_r, want_r) < LOSS_RTOL and rel(got_v, want_v) < 5e-5
+    fr = fv = 0.0
+    for c in batches:                                                     # the fused (no autograd, no host bounce) form
+        a, b = E.eval_losses(model, c.unsqueeze(1).to(DEV))
+        fr += a.item() / len(batches)
+        fv += b.item() / len(batches)
+    assert rel(fr, want_r) < LOSS_RTOL and rel(fv, want_v) < 5e-5
+
+
+def test_checkpoint_resume_is_bitwise_and_reference_layout(golden_dir, tmp_path):
+    from neural_sound_generation_amd import evaluate as E
+    g = golden(golden_dir, "model_tiny.npz")
+    c = torch.from_numpy(g["s0.c"]).to(DEV)
+
+    def fresh():
+        m = build(g).train()
+        return m, FusedTrainStep(m, lr=1e-3, beta=1.0)
+
+    m1, s1 = fresh()
+    for _ in range(3):
+        s1.step(c)
+    m2, s2 = fresh()
+    for _ in range(2):
+        s2.step(c)
+    path = str(tmp_path / "models" / "vqvae" / "ckpt.pth.tar")
+    E.save_checkpoint(None, E.checkpoint_state(2, "vqvae", m2, s2.opt), filename=path)
+    saved = torch.load(path, weights_only=True)
+    assert set(saved) == {"epoch", "arch", "state_dict", "optimizer"}                     # src/main.py:216-220
+    assert [(k, tuple(v.shape)) for k, v in saved["state_dict"].items()] == O.state_keys(*(int(v) for v in g["cfg"]))
+    m3, s3 = fresh()
+    st = E.load_checkpoint(path, m3, s3.opt, map_location=DEV)
+    assert st["epoch"] == 2 and s3.opt.step_count == 2
+    s3.step(c)                                                                            # step 3 after the resume
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b), f"{k} differs after checkpoint resume"
+    # the optimiser state loads into torch.optim.Adam over the same parameters
+    topt = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in m2.parameters()])
+    topt.load_state_dict(saved["optimizer"])
+    assert int(topt.state[topt.param_groups[0]["params"][0]]["step"]) == 2
+
+
+def test_export_reconstruction(golden_dir, tmp_path):
+    from neural_sound_generation_amd import evaluate as E
+    g = golden(golden_dir, "model_tiny.npz")
+    model = build(g).train()
+    c = torch.from_numpy(g["s0.c"]).to(DEV)
+    path = str(tmp_path / "samples" / "ljspeech" / "reconstruction_vqvae.npy")
+    rec = E.export_reconstruction(model, c, path)
+    assert model.training                                                                 # mode restored
+    back = np.load(path, allow_pickle=False)
+    assert back.dtype == np.float32 and back.shape == (c.shape[0], 80, c.shape[3] // 4 * 4) and np.array_equal(back, rec)
+    np.testing.assert_allclose(back, g["eval.x_tilde"][:, 0], rtol=1e-4, atol=2e-6)
+
+
+def test_train_from_disk_loader(tmp_path):
+    """train.txt + .npy data root -> bucketed sampler -> crop/pad collate -> pinned prefetch -> train_vqvae / FusedTrainStep."""
+    from neural_sound_generation_amd import data as Dm
+    from neural_sound_generation_amd.train import train_vqvae
+    root = str(tmp_path / "arctic")
+    Dm.write_synthetic_data_root(root, n_utts=24, min_frames=40, max_frames=90, n_speakers=2, with_audio=False, seed=5)
+    loaders = Dm.get_data_loaders(root, batch_size=4, max_time_steps=64 * Dm.HOP_SIZE, num_workers=0, frame_multiple=4)
+    torch.manual_seed(1)
+    model = M.VQVAE(1, 16, 32).to(DEV)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+
+    class A:
+        beta, log_interval, dataset = 1.0, 1000, "ljspeech"
+    first = train_vqvae(A(), model, opt, Dm.DevicePrefetcher(loaders["train"], DEV), DEV, 0)
+    for _ in range(3):
+        last = train_vqvae(A(), model, opt, Dm.DevicePrefetcher(loaders["train"], DEV), DEV, 1)
+    assert np.isfinite(first) and np.isfinite(last) and last < first                       # it trains
+    step = FusedTrainStep(model, optimizer=opt)
+    n = 0
+    for x, y, c, g_, lens in Dm.DevicePrefetcher(loaders["test"], DEV):
+        assert c.is_cuda and c.shape[1] == 80 and c.shape[2] % 4 == 0
+        losses = step.step(c.unsqueeze(1))
+        assert all(torch.isfinite(l).all() for l in losses)
+        n += 1
+    assert n == len(loaders["test"]) == 1

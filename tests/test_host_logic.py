@@ -98,3 +98,81 @@ def test_shard_batch():
     assert shard_batch(b, 1, 4).flatten().tolist() == [2, 3]
     with pytest.raises(ValueError):
         shard_batch(b, 0, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# on-disk input format, sampler, collate and optimiser-state interchange (8f-3)
+# ---------------------------------------------------------------------------------------------
+def test_data_root_format_split_and_collate(tmp_path):
+    from neural_sound_generation_amd import data as Dm
+    root = str(tmp_path / "ljs")
+    Dm.write_synthetic_data_root(root, n_utts=40, min_frames=30, max_frames=120, n_speakers=3, seed=3)
+    tr = Dm.MelSpecDataSource(root, train=True)
+    te = Dm.MelSpecDataSource(root, train=False)
+    assert tr.multi_speaker and len(tr) + len(te) == 40 and len(te) == 2          # test_size 0.05, sklearn's split
+    assert not set(tr.paths) & set(te.paths)
+    assert all(l % Dm.HOP_SIZE == 0 for l in tr.lengths) and len(tr.speaker_ids) == len(tr)
+    assert [os.path.basename(p) for p in Dm.RawAudioDataSource(root, train=True).paths] == \
+        [os.path.basename(p).replace("mel", "audio") for p in tr.paths]          # the same split for both columns
+    one = Dm.MelSpecDataSource(root, train=True, speaker_id=1)                     # a single speaker of the set
+    assert not one.multi_speaker and 0 < len(one) < len(tr)
+
+    ds = Dm.MelDataset(tr, Dm.RawAudioDataSource(root, train=True))
+    batch = [ds[i] for i in range(6)]
+    col = Dm.Collate(max_time_steps=64 * Dm.HOP_SIZE, frame_multiple=4, rng=np.random.RandomState(0))
+    x, y, c, g, lens = col(batch)
+    B, T = 6, max(min(len(b[1]), 64) // 4 * 4 for b in batch)
+    assert tuple(c.shape) == (B, 80, T) and c.dtype == torch.float32 and c.is_contiguous()
+    assert tuple(x.shape) == (B, 1, T * Dm.HOP_SIZE) and tuple(y.shape) == (B, T * Dm.HOP_SIZE, 1)
+    assert g.dtype == torch.int64 and tuple(g.shape) == (B,) and lens.tolist() == [min(len(b[1]), 64) // 4 * 4 * Dm.HOP_SIZE for b in batch]
+    for i, (xa, ca, _) in enumerate(batch):                                        # crop is frame-aligned on both streams
+        n = lens[i].item() // Dm.HOP_SIZE
+        win = c[i, :, :n].t().numpy()
+        starts = [s for s in range(len(ca) - n + 1) if np.array_equal(ca[s:s + n], win)]
+        assert starts, "the mel crop must be a contiguous window of the utterance"
+        assert any(np.array_equal(xa[s * Dm.HOP_SIZE:(s + n) * Dm.HOP_SIZE], x[i, 0, :n * Dm.HOP_SIZE].numpy()) for s in starts)
+        assert float(c[i, :, n:].abs().sum()) == 0.0                                # zero padding
+    with pytest.raises(ValueError):
+        open(os.path.join(root, "train.txt"), "w").write("a|b|c\n")
+        Dm.MelSpecDataSource(root)
+
+
+def test_similar_length_sampler_groups_by_length():
+    from neural_sound_generation_amd.data import PartialyRandomizedSimilarTimeLengthSampler
+    import random
+    random.seed(0)
+    n = 4099                                                                         # 8 groups of 32 batches + a tail
+    lengths = list(np.random.RandomState(1).randint(100, 10000, size=n))
+    s = PartialyRandomizedSimilarTimeLengthSampler(lengths, batch_size=16)
+    order = list(iter(s))
+    assert sorted(order) == list(range(n)) and len(s) == n                          # a permutation
+    spreads = [np.ptp([lengths[i] for i in order[b:b + 16]]) for b in range(0, 4096, 16)]
+    assert np.mean(spreads) < 0.2 * np.ptp(lengths)                                  # batches hold similar lengths (one group's spread)
+    assert order != list(iter(s))                                                    # and it is randomised
+
+
+def test_flat_adam_state_dict_interchanges_with_torch_adam():
+    torch.manual_seed(0)
+    ref = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    topt = torch.optim.Adam(ref, lr=2e-3)
+    for _ in range(3):
+        for p in ref:
+            p.grad = torch.randn_like(p)
+        topt.step()
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    fopt = FlatAdam(mine, lr=1e-3)
+    fopt.load_state_dict(topt.state_dict())                                          # torch -> flat bucket
+    assert fopt.step_count == 3 and fopt.param_groups[0]["lr"] == 2e-3
+    for i, (p, off) in enumerate(zip(mine, fopt.offsets)):
+        assert torch.equal(fopt.exp_avg[off:off + p.numel()].view_as(p), topt.state[ref[i]]["exp_avg"])
+        assert torch.equal(fopt.exp_avg_sq[off:off + p.numel()].view_as(p), topt.state[ref[i]]["exp_avg_sq"])
+    sd = fopt.state_dict()                                                           # flat bucket -> torch
+    topt2 = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ref], lr=1e-3)
+    topt2.load_state_dict(sd)
+    for p in topt2.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    for p in ref:
+        p.grad = torch.ones_like(p)
+    topt2.step(); topt.step()                                                        # identical continuation
+    for a, b in zip(topt2.param_groups[0]["params"], ref):
+        assert torch.equal(a, b)
