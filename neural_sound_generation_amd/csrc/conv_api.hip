@@ -210,7 +210,7 @@ int classify(const nsg_conv_desc *d, const char *fn)
     const int64_t nin = (int64_t)d->B * d->IH * d->IW * d->C_in, nout = (int64_t)d->B * d->OH * d->OW * d->C_out;
     if (nin >= (1ll << 31) || nout >= (1ll << 31)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: tensor with >= 2^31 elements", fn);
     if (!d->transposed) {
-        if (d->k > 5 || (d->stride != 1 && d->stride != 2) || d->pad < 0 || d->pad >= d->k)
+        if (d->k > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0 || d->pad >= d->k)
             return nsg_fail(NSG_E_UNSUPPORTED, "%s: Conv2d k=%d stride=%d pad=%d not supported", fn, d->k, d->stride, d->pad);
         if (d->OH != (d->IH + 2 * d->pad - d->k) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - d->k) / d->stride + 1)
             return nsg_fail(NSG_E_INVALID, "%s: output extent does not match Conv2d geometry", fn);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int rsub = tid >> 3;
     const int ntaps = (MODE == 0) ? p.KH * p.KW : 4;
     unsigned rbase[AJ];    // BYTE offset of (b, iy0, ix0, c4) (wraps for "negative" pixels; only used when the tap is valid)
-    unsigned tapmask[AJ];  // bit t: tap t of this row lies inside the image
+    unsigned tapmask[AJ];  // bit kh: tap row kh lies inside the image for this row; bit 16+kw: tap column kw does
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int m = m0 + rsub + 32 * j;
@@ -108,13 +108,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             if (MODE == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad; }
             else           { iy0 = ry + py;               ix0 = rx + px; }
             rbase[j] = (unsigned)(((b * p.IH + iy0) * p.IW + ix0) * p.CI + c4) * ES;
-            const int kwl = (MODE == 0) ? p.KW : 2;
+            const int khl = (MODE == 0) ? p.KH : 2, kwl = (MODE == 0) ? p.KW : 2;
             unsigned tm = 0;
-            for (int t = 0; t < ntaps; ++t) {
-                const int kh = t / kwl, kw = t - kh * kwl;
+            for (int kh = 0; kh < khl; ++kh) {
                 const int iy = (MODE == 0) ? iy0 + kh : iy0 - kh;
+                tm |= (unsigned)((iy >= 0) & (iy < p.IH)) << kh;
+            }
+            for (int kw = 0; kw < kwl; ++kw) {
                 const int ix = (MODE == 0) ? ix0 + kw : ix0 - kw;
-                tm |= (unsigned)((iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW)) << t;
+                tm |= (unsigned)((ix >= 0) & (ix < p.IW)) << (16 + kw);
             }
             tapmask[j] = tm;
         }
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     v4f ra0[AJ], rb0[BJ], ra1[AJ], rb1[BJ];   // two register stages: loads run two chunks ahead of the MFMAs
 
     // state of the NEXT chunk to load (advanced incrementally: no divisions in the loop)
-    int g_c0 = 0, g_kh = 0, g_kw = 0, g_t = 0;   // MODE 0: (kh,kw) of the tap; MODE 1: (a,b2) of the class tap; g_t = tap number
+    int g_c0 = 0, g_kh = 0, g_kw = 0;   // MODE 0: (kh,kw) of the tap; MODE 1: (a,b2) of the class tap
     auto gload = [&](v4f (&ra)[AJ], v4f (&rb)[BJ]) {
         int dy, dx, ws;
         if (MODE == 0) { dy = g_kh; dx = g_kw; ws = g_kh * p.KW + g_kw; }
@@ -158,11 +160,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const unsigned tap_b = (unsigned)((dy * p.IW + dx) * p.CI + c0) * ES;   // uniform
         const unsigned wtap_b = (unsigned)(ws * p.CO * p.CI + c0) * ES;         // uniform
         const bool cok = (c0 + c4) < p.CI;
-        const unsigned sel = cok ? (1u << g_t) : 0u;
+        // both the tap's row bit and its column bit must be set; an all-ones pattern (never a mask value) disables the piece
+        const unsigned sel = cok ? ((1u << (g_kh & 15)) | (0x10000u << (g_kw & 15))) : 0xffffffffu;
         const unsigned cm = cok ? 0xffffffffu : 0u;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const unsigned off = (tapmask[j] & sel) ? rbase[j] + tap_b : OOB;
+            const unsigned off = ((tapmask[j] & sel) == sel) ? rbase[j] + tap_b : OOB;
             ra[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
         }
 #pragma unroll
@@ -176,7 +179,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         const int wrap = g_c0 >= p.CI;
         g_c0 = wrap ? 0 : g_c0;
         g_kw += wrap;
-        g_t += wrap;
         const int kwlim = (MODE == 0) ? p.KW : 2;
         const int wrap2 = g_kw >= kwlim;
         g_kw = wrap2 ? 0 : g_kw;
@@ -483,7 +485,7 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
     const uint64_t w_bytes = (uint64_t)(p.mode == 0 ? p.KH * p.KW : 16) * p.CO * p.CI * es;
     if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull)   // 32-bit byte offsets; 0xfffffff0 is the kernel's "reads as zero" offset
         return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: operand of %llu bytes (limit 4 GiB per tensor: split the batch)", (unsigned long long)in_bytes);
-    if ((p.mode == 0 ? p.KH * p.KW : 4) > 32) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: more than 32 taps");
+    if (p.KH > 15 || p.KW > 15) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: kernel extent above 15");
     if (p.epi_add || p.epi_mask) {
         const int epo = p.out_dtype == NSG_BF16 ? 8 : 4;
         if (p.CO % epo != 0 || !nsg_aligned16(p.out) || (p.epi_add && !nsg_aligned16(p.epi_add)) || (p.epi_mask && !nsg_aligned16(p.epi_mask)))
