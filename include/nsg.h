@@ -296,6 +296,27 @@ NSG_API int nsg_adam_step(float *p, const float *g, float *m, float *v, int64_t 
 NSG_API int nsg_debug_dot(const float *x, const float *e, int32_t N, int32_t D, int32_t K, int32_t mode, float *out,
                           void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Latent prior (GatedPixelCNN over the code-index grid)              src/models.py:219-341
+ * Its convolutions are nsg_conv_* calls (rectangular masked kernels embedded in square ones);
+ * these are the element-wise pieces.  fp32, rows [M][channels].
+ * ------------------------------------------------------------------------------------------- */
+
+/* GatedActivation with the class-conditional add folded in (models.py:219-226,268,274):
+ *   y[m][c] = tanh(x[m][c] + cond[b][c]) * sigmoid(x[m][C+c] + cond[b][C+c]),  b = m / rows_per_clip.
+ * x [M][2C], cond [B][2C] or NULL, y [M][C].  C % 4 == 0. */
+NSG_API int nsg_gated_activation_forward(const float *x, const float *cond, float *y, int64_t M, int32_t C,
+                                         int64_t rows_per_clip, void *stream);
+/* dx [M][2C] given dy [M][C] (the gradient w.r.t. cond is the per-clip column sum of dx: nsg_clip_colsum). */
+NSG_API int nsg_gated_activation_backward(const float *x, const float *cond, const float *dy, float *dx, int64_t M,
+                                          int32_t C, int64_t rows_per_clip, void *stream);
+
+/* F.cross_entropy(logits, target) with mean reduction on rows [M][K] (target int64 [M]):
+ * loss_out[0] = mean_m( logsumexp(logits[m]) - logits[m][target[m]] ); dlogits (or NULL) = grad_scale * d loss / d logits. */
+NSG_API size_t nsg_cross_entropy_workspace_bytes(int64_t M);
+NSG_API int nsg_cross_entropy(const float *logits, const int64_t *target, int64_t M, int32_t K, float grad_scale,
+                              float *loss_out, float *dlogits, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,3 +449,45 @@ def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _lib.call("nsg_adam_step", _p(p), _p(g), _p(m), _p(v), c_int64(p.numel()), c_float(lr), c_float(beta1), c_float(beta2),
               c_float(eps), c_int32(step), c_float(grad_scale), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# latent prior (GatedPixelCNN): element-wise pieces
+# ------------------------------------------------------------------------------------------------
+def gated_activation(x, cond=None):
+    """x (..., 2C) NHWC rows, cond (B, 2C) or None -> tanh(a) * sigmoid(b) of the channel halves, (..., C)."""
+    _chk(x, "x")
+    C2 = x.shape[-1]
+    M = x.numel() // C2
+    y = torch.empty(*x.shape[:-1], C2 // 2, dtype=torch.float32, device=x.device)
+    rpc = 1
+    if cond is not None:
+        _chk(cond, "cond")
+        if cond.shape[-1] != C2 or M % cond.shape[0] != 0:
+            raise _lib.NsgError(f"gated_activation: cond {tuple(cond.shape)} does not match x {tuple(x.shape)}")
+        rpc = M // cond.shape[0]
+    _lib.call("nsg_gated_activation_forward", _p(x), _p(cond), _p(y), c_int64(M), c_int32(C2 // 2), c_int64(rpc), _stream())
+    return y
+
+
+def gated_activation_backward(x, cond, dy):
+    _chk(x, "x"); _chk(dy, "dy")
+    C2 = x.shape[-1]
+    M = x.numel() // C2
+    dx = torch.empty_like(x)
+    rpc = M // cond.shape[0] if cond is not None else 1
+    _lib.call("nsg_gated_activation_backward", _p(x), _p(cond), _p(dy), _p(dx), c_int64(M), c_int32(C2 // 2), c_int64(rpc), _stream())
+    return dx
+
+
+def cross_entropy(logits2d, target, want_grad=True, grad_scale=1.0):
+    """mean cross-entropy of rows (M, K) against int64 targets (M,) -> (loss[1], dlogits or None)."""
+    _chk(logits2d, "logits"); _chk(target, "target", torch.int64)
+    M, K = logits2d.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits2d.device)
+    dl = torch.empty_like(logits2d) if want_grad else None
+    nb = _lib.query("nsg_cross_entropy_workspace_bytes", c_int64(M))
+    ws = WS.get(nb, logits2d.device)
+    _lib.call("nsg_cross_entropy", _p(logits2d), _p(target), c_int64(M), c_int32(K), c_float(grad_scale), _p(loss), _p(dl), _p(ws),
+              c_size_t(nb), _stream())
+    return loss, dl

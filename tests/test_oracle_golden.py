@@ -162,3 +162,31 @@ def test_cfg1_model_step(golden_dir):
     for k, v in rec["grads"].items():
         ref = float(g["s0.gnorm." + k])
         assert abs(v.double().norm().item() - ref) <= 1e-4 * ref + 1e-7, k
+
+
+# ---------------------------------------------------------------------------------------------
+# latent prior: the oracle's GatedPixelCNN restatement against the reference's own class
+# ---------------------------------------------------------------------------------------------
+def test_prior_oracle_matches_reference_fixture(golden_dir):
+    from oracle import pixelcnn_oracle as P
+    g = np.load(os.path.join(golden_dir, "prior_tiny.npz"))
+    input_dim, dim, n_layers, n_classes = (int(v) for v in g["cfg"])
+    st = {k[4:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd0.")}
+    assert [(k, tuple(v.shape)) for k, v in st.items()] == P.state_keys(input_dim, dim, n_layers, n_classes)
+    x, label = torch.from_numpy(g["x"]), torch.from_numpy(g["label"])
+    logits, loss, grads, st1 = P.loss_and_grads(st, x, label, n_layers)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-5, atol=1e-6)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    for k, v in grads.items():
+        want = g["grad." + k]
+        np.testing.assert_allclose(v.numpy(), want, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(want).max())), err_msg=k)
+    for k, v in st1.items():                      # mask 'A' zeroed part of layer 0's weights in place, like make_causal
+        assert np.array_equal(v.numpy(), g["sd1." + k]), k
+    # causality: the changed code at (3, 4) leaves every logit at or before (3, 4) in raster order untouched
+    l2 = P.forward(st, torch.from_numpy(g["x2"]), label, n_layers)
+    np.testing.assert_allclose(l2.detach().numpy(), g["logits2"], rtol=1e-5, atol=1e-6)
+    same = (l2.detach() - logits).abs().amax(dim=(0, 1)) == 0
+    assert bool(same[:3].all()) and bool(same[3, :5].all()) and not bool(same[3, 5:].all())
+    # and the non-square generalisation runs (the reference itself cannot: models.py:269,273)
+    xr = torch.randint(0, input_dim, (2, 5, 12), generator=torch.Generator().manual_seed(0))
+    assert tuple(P.forward(st, xr, label, n_layers).shape) == (2, input_dim, 5, 12)
