@@ -317,6 +317,30 @@ NSG_API size_t nsg_cross_entropy_workspace_bytes(int64_t M);
 NSG_API int nsg_cross_entropy(const float *logits, const int64_t *target, int64_t M, int32_t K, float grad_scale,
                               float *loss_out, float *dlogits, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Mel -> waveform inversion (the epoch loop's audio export)   src/main.py:164-197, src/audio_tacotron.py:99-116,142-153
+ * librosa's stft / istft / filters.mel and scipy's lfilter restated; fp32; frame-major spectrograms [B][T][F], F = n_fft/2+1.
+ * ------------------------------------------------------------------------------------------- */
+
+/* S[b][t][f] = max(1e-10, sum_m inv_basis[f][m] * 10^((clip(mel[b][m][t],0,max_abs)*(-min_db)/max_abs + min_db + ref_db)/20))^power
+ * (audio_tacotron.py:242-248 _denormalize, :223 _db_to_amp, :202-206 _mel_to_linear, :115 S ** power).  mel [B][n_mels][T]. */
+NSG_API int nsg_audio_mel_to_linear(const float *mel, const float *inv_basis, float *S, int32_t B, int32_t n_mels, int32_t T,
+                                    int32_t F, float min_level_db, float ref_level_db, float max_abs_value, float power,
+                                    void *stream);
+
+/* Griffin-Lim (audio_tacotron.py:142-153): y [B][hop*(T-1)] from magnitudes S [B][T][F]; u [B][T][F] are the uniform
+ * [0,1) numbers behind the random initial phases exp(2 pi i u).  n_fft in {512, 1024, 2048}, hop divides n_fft. */
+NSG_API size_t nsg_audio_griffin_lim_workspace_bytes(int32_t B, int32_t T, int32_t n_fft);
+NSG_API int nsg_audio_griffin_lim(const float *S, const float *u, float *y, int32_t B, int32_t T, int32_t n_fft, int32_t hop,
+                                  int32_t iters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* X [B][1 + L/hop][F] complex (interleaved re, im) = librosa.stft(y[b], n_fft, hop): centred, reflect-padded, periodic Hann. */
+NSG_API int nsg_audio_stft(const float *y, float *X, int32_t B, int32_t L, int32_t n_fft, int32_t hop, void *stream);
+
+/* y[n] = x[n] + k * y[n-1] per clip (scipy.signal.lfilter([1], [1, -k], x); audio_tacotron.py:28-31), out of place,
+ * |k| < 1.  Chunked with a discarded warm-up of ceil(log 1e-9 / log |k|) samples: chunks are independent to below fp32 rounding. */
+NSG_API int nsg_audio_inv_preemphasis(const float *x, float *y, int32_t B, int32_t L, float k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,11 @@ _SIGS = {
     "nsg_gated_activation_backward": (None, [_P, _P, _P, _P, c_int64, c_int32, c_int64, _P]),
     "nsg_cross_entropy_workspace_bytes": (c_size_t, [c_int64]),
     "nsg_cross_entropy": (None, [_P, _P, c_int64, c_int32, c_float, _P, _P, _P, c_size_t, _P]),
+    "nsg_audio_mel_to_linear": (None, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float, _P]),
+    "nsg_audio_griffin_lim_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "nsg_audio_griffin_lim": (None, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_audio_stft": (None, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    "nsg_audio_inv_preemphasis": (None, [_P, _P, c_int32, c_int32, c_float, _P]),
     "nsg_debug_dot": (None, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
 }
 # entry points declared in include/nsg.h (nsg_debug_vq_forward_valu is a test hook outside the header)

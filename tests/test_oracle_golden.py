@@ -190,3 +190,32 @@ def test_prior_oracle_matches_reference_fixture(golden_dir):
     # and the non-square generalisation runs (the reference itself cannot: models.py:269,273)
     xr = torch.randint(0, input_dim, (2, 5, 12), generator=torch.Generator().manual_seed(0))
     assert tuple(P.forward(st, xr, label, n_layers).shape) == (2, input_dim, 5, 12)
+
+
+# ---------------------------------------------------------------------------------------------
+# mel -> waveform inversion: the numpy restatement's own identities (parity unpinned: no librosa anywhere)
+# ---------------------------------------------------------------------------------------------
+def test_audio_oracle_identities():
+    from oracle import audio_oracle as A
+    from neural_sound_generation_amd import audio as prod
+    mb = A.mel_basis(22050, 1024, 80)
+    assert mb.shape == (80, 513) and mb.dtype == np.float32 and (mb >= 0).all()
+    assert np.array_equal(mb, prod.mel_basis(22050, 1024, 80))                      # the product's constant is the same matrix
+    peaks = mb.argmax(axis=1)
+    assert (np.diff(peaks) > 0).all() and 125 / (22050 / 1024) <= peaks[0] and peaks[-1] <= 7600 / (22050 / 1024)   # triangles ascend inside [fmin, fmax]
+    y = np.random.RandomState(0).randn(256 * 24)
+    X = A.stft(y, 1024, 256)
+    assert X.shape == (513, 25)
+    np.testing.assert_allclose(A.istft(X, 256), y, atol=1e-12)                      # perfect reconstruction (Hann, 75 % overlap)
+    x = np.random.RandomState(1).randn(500)
+    pre = np.concatenate([[x[0]], x[1:] - 0.97 * x[:-1]])                           # preemphasis, audio_tacotron.py:23-26
+    np.testing.assert_allclose(A.inv_preemphasis(pre), x, atol=1e-9)
+    mel = np.random.RandomState(2).rand(80, 16)
+    S = A.linear_from_mel(mel, 22050, 1024, 80)
+    assert S.shape == (513, 16) and (S > 0).all()
+    u = np.random.RandomState(3).rand(513, 16)
+    err = []
+    for it in (0, 5, 30):                                                             # Griffin-Lim: the spectral error falls
+        yy = A.griffin_lim(S, 1024, 256, it, u)
+        err.append(np.linalg.norm(np.abs(A.stft(yy, 1024, 256)) - S) / np.linalg.norm(S))
+    assert err[0] > err[1] > err[2]
