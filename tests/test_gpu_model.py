@@ -545,3 +545,33 @@ def test_bf16_mode_eval_encode_decode():
     r32, v32 = E.eval_losses(m32, c)
     r16, v16 = E.eval_losses(m16, c)
     assert rel(r16.item(), r32.item()) < 2e-2 and rel(v16.item(), v32.item()) < 5e-2
+
+
+def test_epoch_loop_end_to_end(tmp_path, monkeypatch):
+    """src/main.py:128-220 with every stage on this package: data root -> train -> eval -> .npy -> wav -> checkpoint."""
+    from scipy.io import wavfile
+    from neural_sound_generation_amd import data as Dm, evaluate as E
+    from neural_sound_generation_amd.epoch import run_epoch
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / "ljs")
+    Dm.write_synthetic_data_root(root, n_utts=40, min_frames=48, max_frames=80, with_audio=False, seed=11)
+    loaders = Dm.get_data_loaders(root, batch_size=4, max_time_steps=64 * Dm.HOP_SIZE, num_workers=0, frame_multiple=4)
+    torch.manual_seed(1)
+    model = M.VQVAE(1, 16, 32).to(DEV)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+
+    class A:
+        model, dataset, dim, z_dim, beta, log_interval, sampledir = "vqvae", "ljspeech", 16, 32, 1.0, 1000, str(tmp_path / "samples")
+    r1 = run_epoch(A(), model, opt, loaders["train"], loaders["test"], DEV, 1)
+    r2 = run_epoch(A(), model, opt, loaders["train"], loaders["test"], DEV, 2)
+    assert r2["test_loss_recons"] < r1["test_loss_recons"]
+    rec = np.load(r2["reconstruction"], allow_pickle=False)
+    assert rec.dtype == np.float32 and rec.shape[1] == 80 and rec.shape[0] == 2                 # the 5 % test split: 2 clips
+    sr, wav = wavfile.read(r2["wav"])
+    assert sr == 22050 and wav.dtype == np.int16 and len(wav) == 256 * (rec.shape[2] - 1) and int(np.abs(wav).max()) > 1000
+    assert os.path.basename(r2["checkpoint"]) == "checkpoint_ljspeech_16_32.pth.tar"            # main.py:61-65
+    m2 = M.VQVAE(1, 16, 32).to(DEV)
+    st = E.load_checkpoint(r2["checkpoint"], m2, map_location=DEV)
+    assert st["epoch"] == 2 and st["arch"] == "vqvae"
+    for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
