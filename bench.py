@@ -165,7 +165,7 @@ def main():
                         "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
                         "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is taken at N = 1 only
             threads = host_threads()
             v, dt = cpu_baseline(D, K, T, threads)
             cpu = {"value": round(v, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
