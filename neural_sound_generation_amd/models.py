@@ -58,6 +58,7 @@ class VQEmbedding(nn.Module):
         self.ema_decay = ema_decay
         self.ema_eps = ema_eps
         self.search_impl = "mfma"     # "bf16x3" in the bf16 compute mode (set by VQVAE)
+        self.scatter_impl = "f32"     # "bf16x2" in the bf16 compute mode: the codebook-gradient scatter-add on the bf16 pipe
         if ema_decay is not None:
             self.embedding.weight.requires_grad_(False)
             self.register_buffer("ema_count", torch.zeros(z_dim))
@@ -71,7 +72,7 @@ class VQEmbedding(nn.Module):
         z_e_x_ = Fn.to_nhwc(z_e_x)
         z_q_x_, indices = vq_st(z_e_x_, self.embedding.weight.detach(), self.search_impl)
         z_q_x = Fn.to_nchw_view(z_q_x_)
-        z_q_x_bar_ = codebook_lookup(self.embedding.weight, indices).view_as(z_e_x_)
+        z_q_x_bar_ = codebook_lookup(self.embedding.weight, indices, self.scatter_impl).view_as(z_e_x_)
         z_q_x_bar = Fn.to_nchw_view(z_q_x_bar_)
         return z_q_x, z_q_x_bar
 
@@ -152,6 +153,7 @@ class VQVAE(nn.Module):
             # the quantiser's search on the bf16 matrix pipe with split fp32 operands (distances to ~2^-16; the
             # fp32 parity mode keeps the bit-exact search)
             self.codebook.search_impl = "bf16x3"
+            self.codebook.scatter_impl = "bf16x2"
         self.n_speakers = n_speakers
         if n_speakers is not None:
             self.speaker_embedding = nn.Embedding(n_speakers, dim)

@@ -66,16 +66,17 @@ class CodebookLookup(Function):
     torch.index_select(self.embedding.weight, 0, indices) (src/models.py:137-138)."""
 
     @staticmethod
-    def forward(ctx, codebook, indices):
+    def forward(ctx, codebook, indices, impl="f32"):
         ctx.save_for_backward(indices)
         ctx.codebook_rows = codebook.size(0)
+        ctx.impl = impl
         return ops.gather_rows(codebook.detach().contiguous(), indices)
 
     @staticmethod
     def backward(ctx, grad_output):
         (indices,) = ctx.saved_tensors
         g = grad_output.contiguous().view(indices.numel(), -1)
-        return ops.index_add_rows(indices.view(-1), g, ctx.codebook_rows), None
+        return ops.index_add_rows(indices.view(-1), g, ctx.codebook_rows, impl=ctx.impl), None, None
 
 
 class AddPerClip(Function):
@@ -102,6 +103,9 @@ def vq_st(inputs, codebook, impl="mfma"):
     return VectorQuantizationStraightThrough.apply(inputs, codebook, impl)
 
 
+def codebook_lookup(codebook, indices, impl="f32"):
+    return CodebookLookup.apply(codebook, indices, impl)
+
+
 add_per_clip = AddPerClip.apply
-codebook_lookup = CodebookLookup.apply
 __all__ = ["vq", "vq_st", "codebook_lookup"]
