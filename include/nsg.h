@@ -63,7 +63,7 @@ enum {
 /* Geometry of one convolution layer.  transposed = 0: nn.Conv2d(C_in, C_out, k, stride, pad);
  * transposed = 1: nn.ConvTranspose2d(C_in, C_out, k, stride, pad).  (IH,IW) is the layer's input
  * extent, (OH,OW) its output extent; both are given so the library never has to guess.
- * Supported: Conv2d with any k <= 7, stride in {1,2}; ConvTranspose2d with k=4, stride=2, pad=1
+ * Supported: Conv2d with any k <= 7 (rectangular: see k_w), stride in {1,2}; ConvTranspose2d with k=4, stride=2, pad=1
  * (the only transposed geometry on the path: src/models.py:179,182).  C_in and C_out must be
  * multiples of 4 or equal to 1. */
 typedef struct nsg_conv_desc {
@@ -75,6 +75,11 @@ typedef struct nsg_conv_desc {
                       weights.  Single-channel tensors (C == 1: the mel image, the reconstruction and their
                       gradients), biases, weight gradients and the reference-layout weights are always fp32.
                       bf16 needs channel counts that are multiples of 8. */
+    int32_t k_w;   /* 0: square kernel (k x k, pad on both dimensions).  > 0: rectangular Conv2d (stride 1,
+                      C_in > 1): k x k_w taps, padding (pad, pad_w), reference weight layout (C_out, C_in, k, k_w).
+                      A stride-1 output may also be CROPPED at the bottom / right: OH / OW smaller than the full
+                      extent (the pad-then-crop of the prior's masked stacks, src/models.py:268-273). */
+    int32_t pad_w; /* column padding when k_w > 0 */
 } nsg_conv_desc;
 
 NSG_API int nsg_version(void);

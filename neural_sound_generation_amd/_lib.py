@@ -24,7 +24,8 @@ class ConvDesc(Structure):
     """struct nsg_conv_desc (include/nsg.h)."""
     _fields_ = [("B", c_int32), ("IH", c_int32), ("IW", c_int32), ("C_in", c_int32),
                 ("OH", c_int32), ("OW", c_int32), ("C_out", c_int32),
-                ("k", c_int32), ("stride", c_int32), ("pad", c_int32), ("transposed", c_int32), ("dtype", c_int32)]
+                ("k", c_int32), ("stride", c_int32), ("pad", c_int32), ("transposed", c_int32), ("dtype", c_int32),
+                ("k_w", c_int32), ("pad_w", c_int32)]
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)

@@ -199,6 +199,13 @@ inline int ew_blocks(int64_t n)
 
 enum Kind { K_CONV, K_CONVT, K_CONV_C1, K_CONVT_C1 };
 
+// kernel extent / padding per dimension: k, pad are the height's (and the width's for a square kernel, k_w == 0)
+inline int kh_of(const nsg_conv_desc *d) { return d->k; }
+inline int kw_of(const nsg_conv_desc *d) { return d->k_w > 0 ? d->k_w : d->k; }
+inline int ph_of(const nsg_conv_desc *d) { return d->pad; }
+inline int pw_of(const nsg_conv_desc *d) { return d->k_w > 0 ? d->pad_w : d->pad; }
+inline bool rect(const nsg_conv_desc *d) { return d->k_w > 0 && (d->k_w != d->k || d->pad_w != d->pad); }
+
 // validates the descriptor; returns <0 on error, else the layer kind
 int classify(const nsg_conv_desc *d, const char *fn)
 {
@@ -210,11 +217,17 @@ int classify(const nsg_conv_desc *d, const char *fn)
     const int64_t nin = (int64_t)d->B * d->IH * d->IW * d->C_in, nout = (int64_t)d->B * d->OH * d->OW * d->C_out;
     if (nin >= (1ll << 31) || nout >= (1ll << 31)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: tensor with >= 2^31 elements", fn);
     if (!d->transposed) {
-        if (d->k > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0 || d->pad >= d->k)
-            return nsg_fail(NSG_E_UNSUPPORTED, "%s: Conv2d k=%d stride=%d pad=%d not supported", fn, d->k, d->stride, d->pad);
-        if (d->OH != (d->IH + 2 * d->pad - d->k) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - d->k) / d->stride + 1)
+        const int kh = kh_of(d), kw = kw_of(d), ph = ph_of(d), pw = pw_of(d);
+        if (kh > 7 || kw > 7 || (d->stride != 1 && d->stride != 2) || ph < 0 || ph >= kh || pw < 0 || pw >= kw || d->k_w < 0)
+            return nsg_fail(NSG_E_UNSUPPORTED, "%s: Conv2d kernel %dx%d stride=%d pad=(%d,%d) not supported", fn, kh, kw, d->stride, ph, pw);
+        const int full_h = (d->IH + 2 * ph - kh) / d->stride + 1, full_w = (d->IW + 2 * pw - kw) / d->stride + 1;
+        if (d->stride == 1) {   // a stride-1 output may be cropped at the bottom / right (the masked stacks of the prior, models.py:268-273)
+            if (d->OH > full_h || d->OW > full_w) return nsg_fail(NSG_E_INVALID, "%s: output extent exceeds the Conv2d geometry", fn);
+        } else if (d->OH != full_h || d->OW != full_w || rect(d)) {
             return nsg_fail(NSG_E_INVALID, "%s: output extent does not match Conv2d geometry", fn);
+        }
         if (d->C_in == 1) {
+            if (rect(d)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: rectangular kernels need C_in > 1", fn);
             if (!(d->k == 4 && d->stride == 2 && d->pad == 1 && d->C_out % cm == 0 && nsg_c1_stencil_supported(d->C_out)))
                 return nsg_fail(NSG_E_UNSUPPORTED, "%s: C_in=1 needs k=4,stride=2,pad=1, C_out%%%d==0 and C_out<=1024", fn, cm);
             return K_CONV_C1;
@@ -224,7 +237,7 @@ int classify(const nsg_conv_desc *d, const char *fn)
             return nsg_fail(NSG_E_UNSUPPORTED, "%s: stride-2 Conv2d needs k=4,pad=1", fn);
         return K_CONV;
     }
-    if (!(d->k == 4 && d->stride == 2 && d->pad == 1)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: ConvTranspose2d needs k=4,stride=2,pad=1", fn);
+    if (!(d->k == 4 && d->stride == 2 && d->pad == 1) || rect(d)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: ConvTranspose2d needs k=4,stride=2,pad=1", fn);
     if (d->OH != 2 * d->IH || d->OW != 2 * d->IW) return nsg_fail(NSG_E_INVALID, "%s: output extent does not match ConvTranspose2d geometry", fn);
     if (d->C_out == 1) {
         if (d->C_in % cm || !nsg_c1_stencil_supported(d->C_in))
@@ -259,7 +272,7 @@ GatherGemmParams gg_1x1(const void *in, const void *w, const float *bias, void *
     p.in_dtype = in_dtype; p.out_dtype = out_dtype;
     p.B = 1; p.IH = 1; p.IW = (int)M; p.CI = CI;
     p.OH = 1; p.OW = (int)M; p.CO = CO;
-    p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pad_w = 0;
     p.mode = 0; p.M = (int)M; p.RH = 1; p.RW = (int)M;
     p.flags = flags;
     return p;
@@ -272,7 +285,7 @@ extern "C" {
 size_t nsg_packed_weight_floats(const nsg_conv_desc *d)
 {
     if (!d) return 0;
-    const size_t n = (size_t)d->k * d->k * d->C_in * d->C_out;
+    const size_t n = (size_t)kh_of(d) * kw_of(d) * d->C_in * d->C_out;
     // the single-channel layers keep one image as fp32 [C][16] for the stencil kernels whatever d->dtype is
     const bool c1 = (!d->transposed && d->C_in == 1) || (d->transposed && d->C_out == 1);
     return (c1 && d->dtype == NSG_BF16) ? 2 * n : n;
@@ -314,7 +327,7 @@ int nsg_pack_conv_weights_batch(int32_t n, const nsg_conv_desc *descs, const flo
         const int kind = classify(d, "nsg_pack_conv_weights");
         if (kind < 0) return kind;
         NSG_REQUIRE(w[i], NSG_E_INVALID, "nsg_pack_conv_weights: null weights");
-        const int T = d->k * d->k, CI = d->C_in, CO = d->C_out;
+        const int T = kh_of(d) * kw_of(d), CI = d->C_in, CO = d->C_out;
         const int bf = d->dtype == NSG_BF16 ? 1 : 0;
         switch (kind) {
         case K_CONV:  // w[co][ci][t]
@@ -344,7 +357,7 @@ size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d)
     if (!d) return 0;
     const int kind = classify(d, "nsg_conv_workspace_bytes");
     if (kind < 0) return 0;
-    const int T = d->k * d->k;
+    const int T = kh_of(d) * kw_of(d);
     const int64_t Mp = lowres_pixels(d);
     size_t bytes = 0;
     int A, C, taps;
@@ -376,7 +389,7 @@ static int conv_forward_impl(const nsg_conv_desc *d, const void *x, const void *
         p.in_dtype = d->dtype; p.out_dtype = out_dtype;
         p.B = d->B; p.IH = d->IH; p.IW = d->IW; p.CI = d->C_in;
         p.OH = d->OH; p.OW = d->OW; p.CO = d->C_out;
-        p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
+        p.KH = kh_of(d); p.KW = kw_of(d); p.stride = d->stride; p.pad = ph_of(d); p.pad_w = pw_of(d);
         p.flags = flags & (NSG_RELU_IN | NSG_TANH_OUT | NSG_RELU_OUT);
         if (kind == K_CONV) { p.mode = 0; p.RH = d->OH; p.RW = d->OW; }
         else                { p.mode = 1; p.RH = d->IH; p.RW = d->IW; }
@@ -460,14 +473,14 @@ int nsg_conv_dgrad_relu_add(const nsg_conv_desc *d, const void *dy, const void *
         p.in_dtype = d->dtype; p.out_dtype = d->dtype;
         p.B = d->B; p.IH = d->OH; p.IW = d->OW; p.CI = d->C_out;
         p.OH = d->IH; p.OW = d->IW; p.CO = d->C_in;
-        p.KH = d->k; p.KW = d->k;
+        p.KH = kh_of(d); p.KW = kw_of(d);
         p.flags = 0;
         if (kind == K_CONV && d->stride == 1) {
-            p.mode = 0; p.stride = 1; p.pad = d->k - 1 - d->pad; p.RH = d->IH; p.RW = d->IW;  // flipped taps
+            p.mode = 0; p.stride = 1; p.pad = kh_of(d) - 1 - ph_of(d); p.pad_w = kw_of(d) - 1 - pw_of(d); p.RH = d->IH; p.RW = d->IW;  // flipped taps
         } else if (kind == K_CONV) {
-            p.mode = 1; p.stride = 2; p.pad = 1; p.RH = (d->IH + 1) / 2; p.RW = (d->IW + 1) / 2;  // 4/2/1: transposed classes
+            p.mode = 1; p.stride = 2; p.pad = 1; p.pad_w = 1; p.RH = (d->IH + 1) / 2; p.RW = (d->IW + 1) / 2;  // 4/2/1: transposed classes
         } else {
-            p.mode = 0; p.stride = 2; p.pad = 1; p.RH = d->IH; p.RW = d->IW;  // gradient of convT = strided conv
+            p.mode = 0; p.stride = 2; p.pad = 1; p.pad_w = 1; p.RH = d->IH; p.RW = d->IW;  // gradient of convT = strided conv
         }
         p.M = d->B * p.RH * p.RW;
         p.stamps = g_debug_stamps;
@@ -522,7 +535,7 @@ int nsg_conv_wgrad(const nsg_conv_desc *d, const void *x, const void *dy, float 
     }
     WgradParams p = {};
     p.dtype = d->dtype;
-    p.B = d->B; p.KH = d->k; p.KW = d->k; p.stride = d->stride; p.pad = d->pad;
+    p.B = d->B; p.KH = kh_of(d); p.KW = kw_of(d); p.stride = d->stride; p.pad = ph_of(d); p.pad_w = pw_of(d);
     p.Mp = (int)Mp;
     if (kind == K_CONV) {
         p.P = dy; p.PH = d->OH; p.PW = d->OW; p.A = d->C_out;

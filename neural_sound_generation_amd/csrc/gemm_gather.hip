@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             const int ry = rem / p.RW;
             const int rx = rem - ry * p.RW;
             int iy0, ix0;
-            if (MODE == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad; }
+            if (MODE == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad_w; }
             else           { iy0 = ry + py;               ix0 = rx + px; }
             rbase[j] = (unsigned)(((b * p.IH + iy0) * p.IW + ix0) * p.CI + c4) * ES;
             const int khl = (MODE == 0) ? p.KH : 2, kwl = (MODE == 0) ? p.KW : 2;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_f32(const WgradParams p)
             const int py = nsg_div(rem, p.div_pw);
             const int px = rem - py * p.PW;
             const int qy = py * p.stride - p.pad + kh;
-            const int qx = px * p.stride - p.pad + kw;
+            const int qx = px * p.stride - p.pad_w + kw;
             const int ok = (pix < KP) & (m < mend) & ((c0 + cc4) < p.C) & (qy >= 0) & (qy < p.QH) & (qx >= 0) & (qx < p.QW);
             const size_t off = ok ? (((size_t)(b * p.QH + qy) * p.QW + qx) * p.C + c0 + cc4) : 0;
             rq[S][j] = *reinterpret_cast<const v4f *>(gQ + off);
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int ppix = tid / PA8, pa8 = (tid % PA8) * 8;
     const int qpix = tid / QC8, qc8 = (tid % QC8) * 8;
     const bool pa_ok = (a0 + pa8) < p.A, qc_ok = (c0 + qc8) < p.C;
-    const int yoff = kh - p.pad, xoff = kw - p.pad;
+    const int yoff = kh - p.pad, xoff = kw - p.pad_w;
 
     v4f rp0[PJ], rq0[QJ], rp1[PJ], rq1[QJ];   // two register stages (loads run two chunks ahead of the MFMAs)
     int g_mb = mbeg;

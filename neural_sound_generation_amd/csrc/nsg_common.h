@@ -159,7 +159,7 @@ struct GatherGemmParams {
     int in_dtype, out_dtype;   // NSG_F32 / NSG_BF16
     int B, IH, IW, CI;
     int OH, OW, CO;
-    int KH, KW, stride, pad;
+    int KH, KW, stride, pad, pad_w;   // pad = rows, pad_w = columns
     int mode;    // 0: conv gather (iy = ry*stride - pad + kh); 1: transposed 4/2/1, one parity class per blockIdx.y
     int M;       // rows per class = B*RH*RW
     int RH, RW;  // row grid: conv -> (OH,OW); transposed -> (ceil(OH/2), ceil(OW/2))
@@ -181,7 +181,7 @@ struct WgradParams {
     float *partial;      // [nslab][ntaps][A][C]
     int B, PH, PW, A;
     int QH, QW, C;
-    int KH, KW, stride, pad;
+    int KH, KW, stride, pad, pad_w;   // pad = rows, pad_w = columns
     int Mp;         // B*PH*PW
     int slab_rows;  // multiple of 32
     int relu_p, relu_q, onehot;

@@ -100,7 +100,7 @@ KERNEL_TIMER = None  # set to a KernelTimer() to time gather_gemm / wgrad launch
 def _gemm_flops(d: "ConvDesc") -> float:
     """Algorithmic FLOPs of one forward / dgrad / wgrad of layer d: 2 * low-res pixels * k^2 * C_in * C_out."""
     low = d.B * (d.IH * d.IW if d.transposed else d.OH * d.OW)
-    return 2.0 * low * d.k * d.k * d.C_in * d.C_out
+    return 2.0 * low * d.k * (d.k_w if d.k_w > 0 else d.k) * d.C_in * d.C_out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -175,13 +175,19 @@ def debug_dot(x, e, mode):
 # ------------------------------------------------------------------------------------------------
 # convolutions
 # ------------------------------------------------------------------------------------------------
-def conv_desc(B, IH, IW, C_in, C_out, k, stride, pad, transposed=False, dtype=torch.float32) -> ConvDesc:
-    """dtype: storage type of the layer's multi-channel activations and packed weights."""
+def conv_desc(B, IH, IW, C_in, C_out, k, stride, pad, transposed=False, dtype=torch.float32, out_hw=None) -> ConvDesc:
+    """dtype: storage type of the layer's multi-channel activations and packed weights.  k and pad may be (rows, columns)
+    pairs (a rectangular stride-1 Conv2d); out_hw crops a stride-1 output at the bottom / right."""
+    kh, kw = (k if isinstance(k, (tuple, list)) else (k, k))
+    ph, pw = (pad if isinstance(pad, (tuple, list)) else (pad, pad))
     if transposed:
-        OH, OW = (IH - 1) * stride - 2 * pad + k, (IW - 1) * stride - 2 * pad + k
+        OH, OW = (IH - 1) * stride - 2 * ph + kh, (IW - 1) * stride - 2 * pw + kw
     else:
-        OH, OW = (IH + 2 * pad - k) // stride + 1, (IW + 2 * pad - k) // stride + 1
-    return ConvDesc(B, IH, IW, C_in, OH, OW, C_out, k, stride, pad, 1 if transposed else 0, nsg_dtype(dtype))
+        OH, OW = (IH + 2 * ph - kh) // stride + 1, (IW + 2 * pw - kw) // stride + 1
+    if out_hw is not None:
+        OH, OW = out_hw
+    rect = (kh != kw) or (ph != pw)
+    return ConvDesc(B, IH, IW, C_in, OH, OW, C_out, kh, stride, ph, 1 if transposed else 0, nsg_dtype(dtype), kw if rect else 0, pw if rect else 0)
 
 
 def _in_dtype(d: ConvDesc):

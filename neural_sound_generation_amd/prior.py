@@ -7,10 +7,9 @@ GatedPixelCNN(...)` reproduces the reference's initial weights bit for bit, test
 
 How it maps onto the kernels:
   * every convolution is nsg_conv_forward / nsg_conv_dgrad / nsg_conv_wgrad.  The masked stacks use rectangular kernels
-    with asymmetric cropping -- vertical (k//2+1, k) padded (k//2, k//2) and cropped to H rows, horizontal (1, k//2+1)
-    padded (0, k//2) and cropped to W columns (models.py:238-252,268-273); both are exactly a 'same' k x k convolution
-    whose remaining taps are zero, so the rectangular weight is embedded in a zero k x k one (F.pad on the parameter:
-    autograd slices the gradient back) and runs on the square-kernel implicit GEMM;
+    with pad-then-crop -- vertical (k//2+1, k) padded (k//2, k//2) and cropped to H rows, horizontal (1, k//2+1) padded
+    (0, k//2) and cropped to W columns (models.py:238-252,268-273): the conv descriptor's rectangular form (k, k_w, pad,
+    pad_w, cropped OH / OW), so only the taps that exist are computed;
   * GatedActivation with the class-conditional add is one kernel each way (nsg_gated_activation_*);
   * the two embeddings are nsg_gather_rows / nsg_index_add_rows; the cross-entropy of the logits is nsg_cross_entropy.
 All tensors between kernels are fp32 NHWC rows; module inputs / outputs keep the reference's NCHW logical shapes
@@ -34,15 +33,17 @@ from .models import weights_init
 from .vector_quantization import codebook_lookup
 
 
-class _ConvSame(Function):
-    """y = conv2d(x, w, b) with a square odd kernel and 'same' padding on NHWC rows; optional ReLU of the output."""
+class _Conv(Function):
+    """y = conv2d(x, w, b) on NHWC rows, stride 1, kernel (kh, kw) = w's own extent, padding (ph, pw), the output cropped to
+    the input's (H, W) at the bottom / right -- the reference's pad-then-crop of the masked stacks (models.py:268-273) and,
+    for odd square kernels with pad = k // 2, plain 'same' convolution.  Optional ReLU of the output."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu_out):
+    def forward(ctx, x, w, b, pad, relu_out):
         x = x.contiguous()
         B, H, W, Ci = x.shape
-        Co, _, k, _ = w.shape
-        d = ops.conv_desc(B, H, W, Ci, Co, k, 1, k // 2)
+        Co, _, kh, kw = w.shape
+        d = ops.conv_desc(B, H, W, Ci, Co, (kh, kw), 1, pad, out_hw=(H, W))
         wf, wd = ops.pack_weights(d, w.detach().contiguous())
         y = ops.conv_forward(d, x, wf, b.detach(), flags=ops.NSG_RELU_OUT if relu_out else 0)
         ctx.d, ctx.wd, ctx.relu_out, ctx.wshape = d, wd, relu_out, tuple(w.shape)
@@ -57,7 +58,7 @@ class _ConvSame(Function):
             gy = ops.relu_backward_add(gy, None, y)
         dw, db = ops.conv_wgrad(ctx.d, x, gy, ctx.wshape)
         dx = ops.conv_dgrad(ctx.d, gy, ctx.wd) if ctx.needs_input_grad[0] else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _Gate(Function):
@@ -101,14 +102,9 @@ class _CrossEntropy(Function):
         return dl * g, None
 
 
-def _conv(x_nhwc, conv: nn.Conv2d, k: int, rect=None, relu_out: bool = False):
-    """conv with the module's parameters; rect = 'v' / 'h': embed the rectangular masked kernel in a zero k x k one."""
-    w = conv.weight
-    if rect == "v":      # (Co, Ci, k//2+1, k): the rows below the centre are zero
-        w = F.pad(w, (0, 0, 0, k - (k // 2 + 1)))
-    elif rect == "h":    # (Co, Ci, 1, k//2+1): only the centre row, left of and including the centre
-        w = F.pad(w, (0, k - (k // 2 + 1), k // 2, k // 2))
-    return _ConvSame.apply(x_nhwc, w, conv.bias, relu_out)
+def _conv(x_nhwc, conv: nn.Conv2d, relu_out: bool = False):
+    """The module's own (possibly rectangular) kernel and padding, output cropped to the input extent."""
+    return _Conv.apply(x_nhwc, conv.weight, conv.bias, tuple(conv.padding), relu_out)
 
 
 class GatedActivation(nn.Module):
@@ -138,14 +134,13 @@ class GatedMaskedConv2d(nn.Module):
         """x_v, x_h (B, H, W, dim) NHWC rows, h (B,) int64 class labels -> (out_v, out_h) NHWC."""
         if self.mask_type == 'A':
             self.make_causal()
-        k = self.kernel
         cond = codebook_lookup(self.class_cond_embedding.weight, h.view(-1))          # (B, 2 dim)
-        h_vert = _conv(x_v, self.vert_stack, k, rect="v")
+        h_vert = _conv(x_v, self.vert_stack)
         out_v = _Gate.apply(h_vert, cond)
-        h_horiz = _conv(x_h, self.horiz_stack, k, rect="h")
-        v2h = _conv(h_vert, self.vert_to_horiz, 1)
+        h_horiz = _conv(x_h, self.horiz_stack)
+        v2h = _conv(h_vert, self.vert_to_horiz)
         out = _Gate.apply(_Add.apply(v2h, h_horiz), cond)
-        out_h = _conv(out, self.horiz_resid, 1)
+        out_h = _conv(out, self.horiz_resid)
         if self.residual:
             out_h = _Add.apply(out_h, x_h)
         return out_v, out_h
@@ -178,8 +173,8 @@ class GatedPixelCNN(nn.Module):
         x_v, x_h = e, e
         for layer in self.layers:
             x_v, x_h = layer.forward_nhwc(x_v, x_h, label)
-        y = _conv(x_h, self.output_conv[0], 1, relu_out=True)     # the ReLU is fused into the conv's store
-        return _conv(y, self.output_conv[2], 1)
+        y = _conv(x_h, self.output_conv[0], relu_out=True)     # the ReLU is fused into the conv's store
+        return _conv(y, self.output_conv[2])
 
     def forward(self, x, label):
         return Fn.to_nchw_view(self.forward_nhwc(x, label))

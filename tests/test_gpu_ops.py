@@ -276,6 +276,43 @@ def test_conv_forward_dgrad_wgrad(case):
     assert torch.equal(dwg, dwg2), "wgrad must be bitwise reproducible"
 
 
+RECT_CASES = [
+    # (B, H, W, C_in, C_out, (kh, kw), (ph, pw)): output cropped to (H, W) -- the prior's masked stacks (models.py:238-252,268-273)
+    (2, 9, 13, 16, 32, (4, 7), (3, 3)),    # vertical stack, kernel 7
+    (2, 9, 13, 16, 32, (1, 4), (0, 3)),    # horizontal stack, kernel 7
+    (2, 20, 24, 8, 16, (2, 3), (1, 1)),    # vertical stack, kernel 3
+    (1, 6, 40, 8, 16, (1, 2), (0, 1)),     # horizontal stack, kernel 3
+    (2, 7, 9, 8, 8, (3, 5), (1, 2)),       # a plain rectangular 'same' convolution
+]
+
+
+@pytest.mark.parametrize("case", RECT_CASES, ids=str)
+@pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16"])
+def test_rectangular_cropped_conv(case, bf):
+    B, H, W, Ci, Co, (kh, kw), (ph, pw) = case
+    g = torch.Generator().manual_seed(kh * 10 + kw)
+    dt = torch.bfloat16 if bf else torch.float32
+
+    def q(t):
+        return t.to(dt).float()
+    x = q(torch.randn(B, Ci, H, W, generator=g)).requires_grad_(True)
+    w = q(torch.randn(Co, Ci, kh, kw, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, (ph, pw))[:, :, :H, :W]
+    dy = q(torch.randn(y.shape, generator=g))
+    gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
+    d = ops.conv_desc(B, H, W, Ci, Co, (kh, kw), 1, (ph, pw), dtype=dt, out_hw=(H, W))
+    wf, wd = ops.pack_weights(d, gpu(w.detach()))
+    xg, dyg = gpu(nhwc(x.detach())).to(dt), gpu(nhwc(dy)).to(dt)
+    yg = ops.conv_forward(d, xg, wf, gpu(b.detach()))
+    tol = 1e-2 if bf else 2e-5
+    _close(nchw(yg.float().cpu()), y.detach(), tol=tol, what="forward")
+    _close(nchw(ops.conv_dgrad(d, dyg, wd).float().cpu()), gx, tol=tol, what="dgrad")
+    dwg, dbg = ops.conv_wgrad(d, xg, dyg, tuple(w.shape))
+    _close(dwg.cpu(), gw, tol=2e-3 if bf else 2e-5, what="wgrad")
+    _close(dbg.cpu(), gb, tol=1e-4, what="bias grad")
+
+
 @pytest.mark.parametrize("case", [(2, 10, 12, 8, 8, 3, 1, 1, False), (2, 11, 15, 16, 16, 4, 2, 1, False), (2, 6, 7, 16, 16, 4, 2, 1, True),
                                   (2, 20, 31, 1, 8, 4, 2, 1, False), (1, 20, 64, 128, 128, 3, 1, 1, False), (1, 8, 16, 256, 256, 4, 2, 1, False),
                                   (3, 5, 9, 64, 64, 4, 2, 1, True)], ids=str)
