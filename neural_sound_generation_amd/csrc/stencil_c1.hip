@@ -27,16 +27,34 @@ struct C1Geom {
     FastDiv div_segs, div_lh;
 };
 
-// stage the 4 image rows x (2*TW+2) columns a tile needs; out-of-image positions are zero (the conv padding)
-__device__ __forceinline__ void fill_patch(float *patch, const float *__restrict__ img, const C1Geom &g, int b, int ly, int ox0, int tid)
+// The 4 image rows x (2*TW+2) columns a tile needs (out-of-image positions are zero: the conv padding), in two halves so
+// that the NEXT tile's global loads are in flight while the current tile is computed: patch_load -> registers,
+// patch_store -> LDS.  4*(2*TW+2) = 520 values = 3 per thread of 256 (the last partly).
+constexpr int PATCH_VALS = 4 * (2 * TW + 2);
+constexpr int PATCH_PER_THREAD = (PATCH_VALS + 255) / 256;
+__device__ __forceinline__ void patch_load(float (&r)[PATCH_PER_THREAD], const float *__restrict__ img, const C1Geom &g, int b, int ly, int ox0, int tid)
 {
     constexpr int NCOL = 2 * TW + 2;
-    for (int i = tid; i < 4 * NCOL; i += 256) {
-        const int r = i / NCOL, cix = i - r * NCOL;
-        const int y = 2 * ly - 1 + r, x = 2 * ox0 - 1 + cix;
-        float v = 0.f;
-        if (y >= 0 && y < g.HH && x >= 0 && x < g.WW) v = img[((size_t)b * g.HH + y) * g.WW + x];
-        patch[r * PP + cix] = v;
+#pragma unroll
+    for (int q = 0; q < PATCH_PER_THREAD; ++q) {
+        const int i = tid + 256 * q;
+        const int rr = i / NCOL, cix = i - rr * NCOL;
+        const int y = 2 * ly - 1 + rr, x = 2 * ox0 - 1 + cix;
+        const bool ok = (i < PATCH_VALS) & (y >= 0) & (y < g.HH) & (x >= 0) & (x < g.WW);
+        const float v = img[ok ? ((size_t)b * g.HH + y) * g.WW + x : 0];     // clamped, unconditional
+        r[q] = ok ? v : 0.f;
+    }
+}
+__device__ __forceinline__ void patch_store(float *patch, const float (&r)[PATCH_PER_THREAD], int tid)
+{
+    constexpr int NCOL = 2 * TW + 2;
+#pragma unroll
+    for (int q = 0; q < PATCH_PER_THREAD; ++q) {
+        const int i = tid + 256 * q;
+        if (i < PATCH_VALS) {
+            const int rr = i / NCOL, cix = i - rr * NCOL;
+            patch[rr * PP + cix] = r[q];
+        }
     }
 }
 
@@ -92,15 +110,26 @@ __global__ __launch_bounds__(256) void c1_stencil_fwd_kernel(const float *__rest
     }
 
     int buf = 0;
+    float pr[PATCH_PER_THREAD];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load(pr, img, g, b, ly, ox0, tid);
+        patch_store(patch[0], pr, tid);
+    }
+    __syncthreads();
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
         int b, ly, ox0;
         tile_coords(g, tile, b, ly, ox0);
-        fill_patch(patch[buf], img, g, b, ly, ox0, tid);
-        __syncthreads();   // (two buffers: the next fill cannot overtake this tile's readers, they all pass this barrier first)
-        if (!active) continue;
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {                 // the next tile's image rows travel while this tile is computed
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load(pr, img, g, nb, nly, nox0, tid);
+        }
         const int npx = min(TW, g.LW - ox0);
         TO *orow = out + (((size_t)b * g.LH + ly) * g.LW + ox0) * g.C + c0;
-        for (int j = sl; j < npx; j += SL) {
+        for (int j = sl; active && j < npx; j += SL) {
             v2f tp[8];
             read_taps(patch[buf], j, tp);
             v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
@@ -124,6 +153,8 @@ __global__ __launch_bounds__(256) void c1_stencil_fwd_kernel(const float *__rest
                 *reinterpret_cast<v2u *>(dst) = pk;
             }
         }
+        if (nxt < g.ntiles) patch_store(patch[buf ^ 1], pr, tid);   // (its last readers passed the barrier below one tile ago)
+        __syncthreads();
     }
 }
 
@@ -152,15 +183,26 @@ __global__ __launch_bounds__(256) void c1_stencil_wgrad_kernel(const float *__re
         for (int k = 0; k < 8; ++k) acc[c][k] = v2f{0.f, 0.f};
 
     int buf = 0;
+    float pr[PATCH_PER_THREAD];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load(pr, img, g, b, ly, ox0, tid);
+        patch_store(patch[0], pr, tid);
+    }
+    __syncthreads();
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
         int b, ly, ox0;
         tile_coords(g, tile, b, ly, ox0);
-        fill_patch(patch[buf], img, g, b, ly, ox0, tid);
-        __syncthreads();
-        if (!active) continue;
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load(pr, img, g, nb, nly, nox0, tid);
+        }
         const int npx = min(TW, g.LW - ox0);
         const TI *trow = t + (((size_t)b * g.LH + ly) * g.LW + ox0) * g.C + c0;
-        for (int j0 = sl; j0 < npx; j0 += 4 * SL) {
+        for (int j0 = sl; active && j0 < npx; j0 += 4 * SL) {
             float tv[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -193,6 +235,8 @@ __global__ __launch_bounds__(256) void c1_stencil_wgrad_kernel(const float *__re
                 }
             }
         }
+        if (nxt < g.ntiles) patch_store(patch[buf ^ 1], pr, tid);
+        __syncthreads();
     }
     // ---- reduce over the block's slots, one of the thread's 4 channels per pass: red[v][tid], v = tap (16 = column sum) ----
     float *dst = partial + (size_t)blockIdx.x * g.C * 17;
