@@ -99,9 +99,36 @@ class FusedTrainStep:
         g = ops.index_add_rows(idx, dq, K, impl=self.scatter_impl)
         ops.add(g, None, out=self.g_code)
 
+    # ---- HIP graph of forward + backward (optional) ------------------------------------------------------------
+    # The ~140 kernel launches that fill the gradient bucket are captured once and replayed (hipGraph through
+    # torch.cuda.CUDAGraph: every ctypes launch goes to torch's current stream, which is the capturing stream).  The
+    # optimiser step stays outside (its bias-correction scalars change every step), as do the collectives.
+    @torch.no_grad()
+    def capture(self, c: torch.Tensor, g: torch.Tensor | None = None, warmup: int = 2):
+        """Capture forward_backward for inputs of c's shape.  The warm-up steps are REAL training steps."""
+        for _ in range(warmup):               # first-use work (LDS attributes, workspace growth) must not be captured
+            self.step(c, g)
+        self._static_c = c.clone()
+        self._static_g = g.clone() if g is not None else None
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_losses = self.forward_backward(self._static_c, self._static_g)
+        return self
+
+    def _replay(self, c, g):
+        self._static_c.copy_(c)
+        if g is not None:
+            self._static_g.copy_(g)
+        self._graph.replay()
+        return self._graph_losses
+
     @torch.no_grad()
     def step(self, c: torch.Tensor, g: torch.Tensor | None = None):
-        losses = self.forward_backward(c, g)
+        if getattr(self, "_graph", None) is not None and c.shape == self._static_c.shape and (g is None) == (self._static_g is None):
+            losses = self._replay(c, g)
+        else:
+            losses = self.forward_backward(c, g)
         if self.world > 1:
             nsg_dist.allreduce_sum_(self.opt.flat_grad, self.group)
             if self.ema:
