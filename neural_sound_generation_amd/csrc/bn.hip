@@ -79,69 +79,69 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T *__restri
     }
 }
 
-// 32 lanes per channel.  Lane j owns a contiguous run of slabs and forms (n, mean, M2) of the run in double as
-//   n = sum n_s,  mean = sum n_s m_s / n,  M2 = sum ( q_s + n_s (m_s - mean)^2 )
-// (the pooled-variance identity; no division chain), lane 0 then pools the 32 runs the same way, in lane
-// order.  Fixed order -> bitwise reproducible.
+// Fixed-shape sum of one double per thread over the 256 threads of a block (deterministic); result in every thread.
+// Xor-butterflies inside each wave (no barrier), then the 4 wave totals through LDS in wave order.
+__device__ __forceinline__ double block_sum256(double v, double *red, int tid)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const double r = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return r;
+}
+
+// One block per 4 channels; thread j takes slabs j, j+256, ... (16-byte loads of the 4 channels' partials, all issued
+// before any arithmetic: one memory latency), then two fixed-shape tree sums per channel in double:
+//   n = sum n_s,  mean = sum n_s m_s / n,  M2 = sum ( q_s + n_s (m_s - mean)^2 )       (the pooled-variance identity)
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ partial, int nslab, int slab_rows, int64_t M,
                                                              int C, float eps, float momentum, float *mean, float *invstd,
                                                              float *running_mean, float *running_var)
 {
-    __shared__ double sn[256], smu[256], sm2[256];
+    constexpr int PER = MAX_SLABS / 256;
+    __shared__ double red[256];
     const int tid = threadIdx.x;
-    const int j = tid & 31;
-    const int c = blockIdx.x * 8 + (tid >> 5);
-    double n = 0.0, mu = 0.0, m2 = 0.0;
-    if (c < C) {
-        constexpr int PER_MAX = MAX_SLABS / 32;
-        const int per = (nslab + 31) / 32;          // <= PER_MAX
-        const int s0 = j * per, s1 = min(nslab, s0 + per);
-        // all loads first (independent), then the arithmetic: one memory latency instead of 2*per of them
-        float ms[PER_MAX], qs[PER_MAX];
+    const int c0 = blockIdx.x * 4;
+    v4f ms[PER], qs[PER];
+    float ns[PER];
 #pragma unroll
-        for (int i = 0; i < PER_MAX; ++i) {
-            const int sc = min(s0 + i, nslab - 1);   // unconditional (clamped) loads: nothing waits on a branch
-            ms[i] = partial[(size_t)sc * 2 * C + c];
-            qs[i] = partial[(size_t)sc * 2 * C + C + c];
-        }
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + 256 * i;
+        const int sc = s < nslab ? s : nslab - 1;                     // clamped, unconditional loads
+        ms[i] = *reinterpret_cast<const v4f *>(partial + (size_t)sc * 2 * C + c0);
+        qs[i] = *reinterpret_cast<const v4f *>(partial + (size_t)sc * 2 * C + C + c0);
+        const int64_t r0 = (int64_t)sc * slab_rows;
+        ns[i] = s < nslab ? (float)(min(M, r0 + slab_rows) - r0) : 0.f;
+    }
+    double mu[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < PER_MAX; ++i) {
-            const int s = s0 + i;
-            if (i < per && s < s1) {
-                const int64_t r0 = (int64_t)s * slab_rows;
-                const double ns = (double)(min(M, r0 + slab_rows) - r0);
-                n += ns;
-                t += ns * (double)ms[i];
-            }
-        }
-        if (n > 0.0) mu = t / n;
-#pragma unroll
-        for (int i = 0; i < PER_MAX; ++i) {
-            const int s = s0 + i;
-            if (i < per && s < s1) {
-                const int64_t r0 = (int64_t)s * slab_rows;
-                const double ns = (double)(min(M, r0 + slab_rows) - r0);
-                const double dl = (double)ms[i] - mu;
-                m2 += (double)qs[i] + ns * dl * dl;
-            }
-        }
+        for (int i = 0; i < PER; ++i) t += (double)ns[i] * (double)ms[i][e];
+        mu[e] = block_sum256(t, red, tid) / (double)M;
     }
-    sn[tid] = n; smu[tid] = mu; sm2[tid] = m2;
-    __syncthreads();
-    if (j != 0 || c >= C) return;
-    double nt = 0.0, t = 0.0;
-    for (int k = 0; k < 32; ++k) { nt += sn[tid + k]; t += sn[tid + k] * smu[tid + k]; }
-    mu = t / nt;
-    m2 = 0.0;
-    for (int k = 0; k < 32; ++k) { const double dl = smu[tid + k] - mu; m2 += sm2[tid + k] + sn[tid + k] * dl * dl; }
-    const double var_b = m2 / (double)M;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var_b + (double)eps));
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-    if (running_var) {
-        const double var_u = M > 1 ? m2 / (double)(M - 1) : var_b;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const double dl = (double)ms[i][e] - mu[e];
+            t += ns[i] > 0.f ? (double)qs[i][e] + (double)ns[i] * dl * dl : 0.0;
+        }
+        const double m2 = block_sum256(t, red, tid);
+        if (tid == 0 && c0 + e < C) {
+            const int c = c0 + e;
+            const double var_b = m2 / (double)M;
+            mean[c] = (float)mu[e];
+            invstd[c] = (float)(1.0 / sqrt(var_b + (double)eps));
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu[e];
+            if (running_var) {
+                const double var_u = M > 1 ? m2 / (double)(M - 1) : var_b;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+            }
+        }
     }
 }
 
@@ -285,25 +285,34 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T *__restrict
     }
 }
 
+// dbeta[c] = sum_s partial[s][c], dgamma[c] = sum_s partial[s][C + c]: one block per 4 channels, tree sums in double
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta)
 {
-    __shared__ double r1[256], r2[256];
+    constexpr int PER = MAX_SLABS / 256;
+    __shared__ double red[256];
     const int tid = threadIdx.x;
-    const int j = tid & 31;
-    const int c = blockIdx.x * 8 + (tid >> 5);
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        const int per = (nslab + 31) / 32;
-        const int b0 = j * per, b1 = min(nslab, b0 + per);
-        if (b1 > b0) nsg_strided_sum2(partial + (size_t)b0 * 2 * C + c, partial + (size_t)b0 * 2 * C + C + c, (size_t)2 * C, b1 - b0, s1, s2);
+    const int c0 = blockIdx.x * 4;
+    v4f a[PER], b[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + 256 * i;
+        const int sc = s < nslab ? s : nslab - 1;
+        a[i] = *reinterpret_cast<const v4f *>(partial + (size_t)sc * 2 * C + c0);
+        b[i] = *reinterpret_cast<const v4f *>(partial + (size_t)sc * 2 * C + C + c0);
     }
-    r1[tid] = s1; r2[tid] = s2;
-    __syncthreads();
-    if (j != 0 || c >= C) return;
-    s1 = 0.0; s2 = 0.0;
-    for (int k = 0; k < 32; ++k) { s1 += r1[tid + k]; s2 += r2[tid + k]; }
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const bool ok = tid + 256 * i < nslab;
+            t1 += ok ? (double)a[i][e] : 0.0;
+            t2 += ok ? (double)b[i][e] : 0.0;
+        }
+        const double s1 = block_sum256(t1, red, tid);
+        const double s2 = block_sum256(t2, red, tid);
+        if (tid == 0 && c0 + e < C) { dbeta[c0 + e] = (float)s1; dgamma[c0 + e] = (float)s2; }
+    }
 }
 
 // dx = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), slab-structured; optionally also the per-slab
@@ -374,24 +383,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__
     }
 }
 
+// out[c] = sum_s partial[s][c]: one block per 4 channels
 __global__ __launch_bounds__(256) void slab_sum_final_kernel(const float *__restrict__ partial, int nslab, int C, float *out)
 {
+    constexpr int PER = MAX_SLABS / 256;
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    const int j = tid & 31;
-    const int c = blockIdx.x * 8 + (tid >> 5);
-    double s = 0.0;
-    if (c < C) {
-        const int per = (nslab + 31) / 32;
-        const int b0 = j * per, b1 = min(nslab, b0 + per);
-        if (b1 > b0) s = nsg_strided_sum<double>(partial + (size_t)b0 * C + c, (size_t)C, b1 - b0);
+    const int c0 = blockIdx.x * 4;
+    v4f a[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + 256 * i;
+        a[i] = *reinterpret_cast<const v4f *>(partial + (size_t)(s < nslab ? s : nslab - 1) * C + c0);
     }
-    red[tid] = s;
-    __syncthreads();
-    if (j != 0 || c >= C) return;
-    s = 0.0;
-    for (int k = 0; k < 32; ++k) s += red[tid + k];
-    out[c] = (float)s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) t += (tid + 256 * i < nslab) ? (double)a[i][e] : 0.0;
+        const double sm = block_sum256(t, red, tid);
+        if (tid == 0 && c0 + e < C) out[c0 + e] = (float)sm;
+    }
 }
 
 inline int ew_blocks(int64_t n) { return (int)(nsg_cdiv(n, 256) > 4096 ? 4096 : (nsg_cdiv(n, 256) < 1 ? 1 : nsg_cdiv(n, 256))); }
@@ -440,7 +452,7 @@ int nsg_bn_stats(const void *x, int64_t M, int32_t C, int32_t dtype, float eps, 
         hipLaunchKernelGGL((bn_stats_partial_kernel<bf16_t>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), M, C, g.rows, partial);
     else
         hipLaunchKernelGGL((bn_stats_partial_kernel<float>), dim3(g.nslab), dim3(256), 0, s, reinterpret_cast<const float *>(x), M, C, g.rows, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, g.rows, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, g.rows, M, C, eps,
                        momentum, mean, invstd, running_mean, running_var);
     return nsg_check_launch("bn_stats");
 }
@@ -497,18 +509,18 @@ int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const flo
     if (dtype == NSG_BF16) {
         typedef bf16_t T;
         hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
-        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
         // the stage-1 partials have been consumed by bn_bwd_final (stream order): the buffer is reused for the dx column sums
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
                            dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
     } else {
         typedef float T;
         hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
-        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
                            dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
     }
-    if (dx_colsum) hipLaunchKernelGGL(slab_sum_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, g.nslab, C, dx_colsum);
+    if (dx_colsum) hipLaunchKernelGGL(slab_sum_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dx_colsum);
     return nsg_check_launch("bn_backward");
 }
 
