@@ -194,7 +194,9 @@ __global__ void bn_eval_stats_kernel(const float *rm, const float *rv, int C, fl
     }
 }
 
-// y = (x-mean)*invstd*gamma + beta  [relu]  [+ (relu) residual];   x/residual of type TX, y of type TY
+// y = (x-mean)*invstd*gamma + beta  [relu]  [+ (relu) residual];   x/residual of type TX, y of type TY.
+// The grid stride is a multiple of the row length (launcher), so a thread keeps its W channels: their parameters are
+// loaded once, not per element (the kernel was instruction-bound on those loads: 3.7 TB/s on tensors beyond the MALL).
 template <typename TX, typename TY>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TX *__restrict__ x, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ gamma,
@@ -204,13 +206,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX *__restrict__ x,
     // relu bit 0: ReLU right after the affine map; bit 1: ReLU of the final value (after the residual add)
     const int relu_bn = relu & 1, relu_out = relu & 2;
     constexpr int W = Width<TX, TY>::W;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CW) * W;
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % CW) * W;
+    float mu[W], sc[W], be[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) { mu[e] = mean[c + e]; sc[e] = invstd[c + e] * gamma[c + e]; be[e] = beta[c + e]; }
+    for (int64_t i = i0; i < nw; i += (int64_t)gridDim.x * blockDim.x) {
         float xv[W], o[W];
         ldw<TX, W>(x + i * W, xv);
 #pragma unroll
         for (int e = 0; e < W; ++e) {
-            float t = (xv[e] - mean[c + e]) * (invstd[c + e] * gamma[c + e]) + beta[c + e];
+            float t = (xv[e] - mu[e]) * sc[e] + be[e];
             if (relu_bn) t = fmaxf(t, 0.f);
             o[e] = t;
         }
@@ -480,7 +486,16 @@ int nsg_bn_apply(const void *x, const float *mean, const float *invstd, const fl
     const int W = (dtype == NSG_BF16 || y_dtype == NSG_BF16) ? 8 : 4;
     NSG_REQUIRE(C % W == 0, NSG_E_UNSUPPORTED, "nsg_bn_apply: C=%d must be a multiple of %d", C, W);
     const int64_t nw = M * C / W;
-    const dim3 grid(ew_blocks(nw)), blk(256);
+    // grid stride (blocks * 256) must be a multiple of the row length CW = C / W so that a thread keeps its channels
+    int blocks = ew_blocks(nw);
+    {
+        const int CW = C / W;
+        int a = CW, b = 256;
+        while (b) { const int t = a % b; a = b; b = t; }      // a = gcd(CW, 256)
+        const int mult = CW / a;
+        blocks = (blocks + mult - 1) / mult * mult;
+    }
+    const dim3 grid(blocks), blk(256);
 #define NSG_BN_APPLY(TX, TY)                                                                                             \
     hipLaunchKernelGGL((bn_apply_kernel<TX, TY>), grid, blk, 0, s, reinterpret_cast<const TX *>(x), mean, invstd, gamma, \
                        beta, reinterpret_cast<const TX *>(residual), reinterpret_cast<TY *>(y), nw, C / W, relu, relu_residual)
