@@ -34,9 +34,130 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float seed, f
     }
 }
 
+// The bf16 implicit-GEMM main loop with its memory side removed: per 128 x 128 x 64 chunk every thread writes 8 staged
+// 16-byte pieces to LDS (register contents, no global loads), the workgroup barriers, and every wave reads its 16
+// fragments and issues its 16 v_mfma_f32_32x32x16_bf16 -- exactly gather_gemm's LDS / barrier / MFMA traffic (pitch 36
+// floats, double-buffered, two workgroups per CU).  Its rate is the ceiling the LDS-staged 128 x 128 design can reach.
+// mode 0: stores + barrier + reads + MFMA; 1: no stores (reads + MFMA + barrier); 2: MFMA only.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void lds_fed_loop_kernel(int chunks, int mode, float *sink)
+{
+    constexpr int PITCH = 36;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][256 rows][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int rsub = tid >> 3, piece = (tid & 7) * 4;
+    v4f stage[8];
+    for (int j = 0; j < 8; ++j) stage[j] = v4f{(float)tid * 1e-3f, (float)j, 1.f, -1.f};
+    v16f acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = tid; i < 2 * 256 * PITCH; i += 256) smem[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    for (int it = 0; it < chunks; ++it) {
+        const int cur = it & 1;
+        const float *a_base = smem + cur * 256 * PITCH + (wr * 64 + l31) * PITCH + 4 * h;
+        const float *b_base = smem + cur * 256 * PITCH + (128 + wc * 64 + l31) * PITCH + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v4f a[2], b[2];
+            if (mode < 2) {
+                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const v4f *>(a_base + i * 32 * PITCH + kk * 8);
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const v4f *>(b_base + j * 32 * PITCH + kk * 8);
+            } else {
+                a[0] = a[1] = stage[kk]; b[0] = b[1] = stage[kk + 4];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+        }
+        if (mode == 0) {
+            float *dst = smem + (cur ^ 1) * 256 * PITCH;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<v4f *>(dst + (rsub + 32 * j) * PITCH + piece) = stage[j];
+        }
+        if (mode < 2) __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    sink[blockIdx.x * 256 + tid] = s;
+}
+
+// The same with 8 waves on a 256 x 128 tile (one workgroup per CU, still two waves per SIMD, each wave 64 x 64): the weight
+// tile is staged once for twice the rows: 6 stores per thread per chunk instead of 8.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void lds_fed_loop8_kernel(int chunks, int mode, float *sink)
+{
+    constexpr int PITCH = 36;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][384 rows][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;   // wr 0..3, wc 0..1
+    const int rsub = tid >> 3, piece = (tid & 7) * 4;                          // rsub 0..63
+    v4f stage[6];
+    for (int j = 0; j < 6; ++j) stage[j] = v4f{(float)tid * 1e-3f, (float)j, 1.f, -1.f};
+    v16f acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = tid; i < 2 * 384 * PITCH; i += 512) smem[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    for (int it = 0; it < chunks; ++it) {
+        const int cur = it & 1;
+        const float *a_base = smem + cur * 384 * PITCH + (wr * 64 + l31) * PITCH + 4 * h;
+        const float *b_base = smem + cur * 384 * PITCH + (256 + wc * 64 + l31) * PITCH + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v4f a[2], b[2];
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const v4f *>(a_base + i * 32 * PITCH + kk * 8);
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const v4f *>(b_base + j * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+        }
+        if (mode == 0) {
+            float *dst = smem + (cur ^ 1) * 384 * PITCH;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f *>(dst + (rsub + 64 * j) * PITCH + piece) = stage[j];
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    sink[blockIdx.x * 512 + tid] = s;
+}
+
 }  // namespace
 
 extern "C" {
+
+NSG_API int nsg_debug_lds_fed_loop8(int32_t blocks, int32_t chunks, int32_t mode, float *sink, void *stream)
+{
+    NSG_REQUIRE(blocks > 0 && chunks > 0 && sink, NSG_E_INVALID, "nsg_debug_lds_fed_loop8: bad argument");
+    const size_t lds = (size_t)2 * 384 * 36 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_fed_loop8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return nsg_fail((int)e, "nsg_debug_lds_fed_loop8: cannot reserve LDS");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lds_fed_loop8_kernel, dim3(blocks), dim3(512), lds, (hipStream_t)stream, chunks, mode, sink);
+    return nsg_check_launch("lds_fed_loop8_kernel");
+}
+
+// blocks workgroups x chunks chunks of 128 x 128 x 64 (2 * 128 * 128 * 64 flop each); sink: blocks * 256 floats
+NSG_API int nsg_debug_lds_fed_loop(int32_t blocks, int32_t chunks, int32_t mode, float *sink, void *stream)
+{
+    NSG_REQUIRE(blocks > 0 && chunks > 0 && sink, NSG_E_INVALID, "nsg_debug_lds_fed_loop: bad argument");
+    const size_t lds = (size_t)2 * 256 * 36 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_fed_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return nsg_fail((int)e, "nsg_debug_lds_fed_loop: cannot reserve LDS");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lds_fed_loop_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, chunks, mode, sink);
+    return nsg_check_launch("lds_fed_loop_kernel");
+}
+
 
 // sink: blocks*256 floats, stamps: blocks*2 u64 (shader-cycle delta, 100 MHz-tick delta per block)
 NSG_API int nsg_debug_mfma_peak(int32_t blocks, int32_t iters, float *sink, unsigned long long *stamps, void *stream)

@@ -36,7 +36,7 @@ namespace {
 constexpr int LDS_PITCH = 36;   // floats per staged row (32 + 4 pad)
 
 template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gather_gemm_kernel(const GatherGemmParams p)
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2))) void gather_gemm_kernel(const GatherGemmParams p)
 {
     constexpr int EPV = 16 / (int)sizeof(TI);   // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
     constexpr int KC = 8 * EPV;                 // channels per K-chunk: 128 bytes of a row
@@ -46,10 +46,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     TO *__restrict__ gout = reinterpret_cast<TO *>(p.out);
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int AJ = BM / 32;  // float4 rows per thread for A
-    constexpr int BJ = BN / 32;
+    constexpr int NT = 64 * WM * WN;     // threads: 4 waves (128-row tiles) or 8 waves (the 256 x 128 tile, one workgroup per CU)
+    constexpr int RPP = NT / 8;          // rows staged per pass of the block (8 threads per 128-byte row)
+    constexpr int AJ = BM / RPP;         // 16-byte pieces per thread for A
+    constexpr int BJ = BN / RPP;
     constexpr int CP = BN + 4;   // epilogue staging pitch (floats)
-    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert((WM * WN == 4 || WM * WN == 8) && BM % RPP == 0 && BN % RPP == 0, "4 or 8 waves per block");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                         // [2][BM][36]
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     unsigned tapmask[AJ];  // bit kh: tap row kh lies inside the image for this row; bit 16+kw: tap column kw does
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int m = m0 + rsub + 32 * j;
+        const int m = m0 + rsub + RPP * j;
         rbase[j] = 0;
         tapmask[j] = 0;
         if (m < p.M) {
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     unsigned wmask[BJ];    // all ones when column n exists, else zero
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int n = n0 + rsub + 32 * j;
+        const int n = n0 + rsub + RPP * j;
         wbase[j] = (unsigned)(n * p.CI + c4) * ES;
         wmask[j] = n < p.CO ? 0xffffffffu : 0u;
     }
     // ---- output row offsets ----
-    for (int t = tid; t < BM; t += 256) {
+    for (int t = tid; t < BM; t += NT) {
         const int m = m0 + t;
         int off = -1;
         if (m < p.M) {
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
             }
-            *reinterpret_cast<v4f *>(a + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = v;
+            *reinterpret_cast<v4f *>(a + (rsub + RPP * j) * LDS_PITCH + (tid & 7) * 4) = v;
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<v4f *>(b + (rsub + 32 * j) * LDS_PITCH + (tid & 7) * 4) = rb[j];
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<v4f *>(b + (rsub + RPP * j) * LDS_PITCH + (tid & 7) * 4) = rb[j];
     };
 
     v16f acc[TM][TN];
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
     const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);
     constexpr int NV = BN / EPO;     // 16-byte pieces per tile row; divides 256, so a thread keeps its columns
-    static_assert(256 % NV == 0, "a thread's column group must not change from row to row");
+    static_assert(NT % NV == 0, "a thread's column group must not change from row to row");
     const int cq = (tid % NV) * EPO;
     const int col = n0 + cq;
     float bv[EPO];
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const TO *__restrict__ epi_add = reinterpret_cast<const TO *>(p.epi_add);     // (launcher: only with full 16-byte pieces)
     const TO *__restrict__ epi_mask = reinterpret_cast<const TO *>(p.epi_mask);
     if (col < p.CO) {
-        constexpr int RSTEP = 256 / NV;          // tile rows covered per pass of the block
+        constexpr int RSTEP = NT / NV;           // tile rows covered per pass of the block
         constexpr int RI = BM / RSTEP;           // passes
         constexpr int GRP = RI < 8 ? RI : 8;     // the fused add / mask operands of GRP passes are fetched together
         const bool fuse_add = full_vec && epi_add != nullptr, fuse_mask = full_vec && epi_mask != nullptr;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     //      bn_stats_from_tiles -- saves a full read pass over the conv output.  One LDS pass: sums of
     //      (v - pivot) and (v - pivot)^2 with pivot = the tile's first row (a sample of the column, so
     //      no cancellation); written as (count, sum v, sum (v - mean_tile)^2) ----
-    if (p.stats != nullptr) {
+    if constexpr (NT == 256) if (p.stats != nullptr) {
         constexpr int PARTS = 256 / BN;          // threads per column
         constexpr int RPP = BM / PARTS;          // rows per part
         float *red = smem + BM * CP;             // [2][256] scratch behind the staging tile
@@ -443,7 +445,7 @@ int launch_one(const GatherGemmParams &p, hipStream_t s)
         if (e != hipSuccess) return nsg_fail((int)e, "gather_gemm: cannot reserve %zu bytes of LDS", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU>), grid, dim3(64 * WM * WN), lds, s, p);
     return nsg_check_launch("gather_gemm");
 }
 
@@ -455,20 +457,31 @@ int launch_cfg(const GatherGemmParams &p, hipStream_t s)
     return relu ? launch_one<TI, TO, WM, WN, TM, TN, 1, true>(p, s) : launch_one<TI, TO, WM, WN, TM, TN, 1, false>(p, s);
 }
 
+static int g_gather_tile8 = 0;   // off: faster in isolation on random data, slower inside the training step (see launch_typed)
+
 template <typename TI, typename TO>
 int launch_typed(const GatherGemmParams &p, hipStream_t s)
 {
-    // (A 256 x 128 tile -- 128 x 64 per wave, one workgroup per CU -- was built and measured: 480-570 vs 600-640 TFLOP/s on
-    // random bf16 data, with or without sched_group_barrier-pinned fragment prefetch.  Per 128x128x64 chunk the LDS
-    // array is busy ~100 % of the MFMA time already (32 ds_write_b128 at 13 cycles + 64 ds_read_b128 at 4 per
-    // workgroup, two workgroups per CU), so the kernel is LDS-fed-bound; the bigger tile trims that by a quarter but
-    // loses the second wave per SIMD that hides the read latency.  See DESIGN.md 3.1b.)
+    if constexpr (sizeof(TI) == 2) {
+        // bf16: 256 x 128 tile on EIGHT waves (64 x 64 per wave as below, still two waves per SIMD, one workgroup per CU): the
+        // weight tile is staged once for twice the rows, 6 LDS stores per thread per chunk instead of 8.  The LDS-only
+        // probe (scripts/lds_fed_probe.py) puts this layout's ceiling at 1.28 PFLOP/s against 1.07 for two 128 x 128
+        // workgroups; a 4-wave 256 x 128 tile (128 x 64 per wave, ONE wave per SIMD) measured slower than either.
+        // Measured: in isolation on random data (scripts/ab_gather_tile8.py) +21 % on the 4x4/2 conv, +4..6 % on 3x3, -20 % on the
+        // memory-bound 1x1, -10 % on the transposed classes; but INSIDE the training step (scripts/ab_step_tile8.py, the sparse
+        // post-ReLU operands and back-to-back launches of the real thing) 601 vs 639 TFLOP/s over the step's launches at 64
+        // clips, 617 vs 640 at 128.  Kept behind nsg_debug_set_gather_tile8, default off.
+        if (g_gather_tile8 && p.mode == 0 && p.KH * p.KW * p.CI >= 1024 && p.CO > 64 && p.stats == nullptr && p.M >= 256 * 256)
+            return launch_cfg<TI, TO, 4, 2, 2, 2>(p, s);
+    }
     if (p.CO > 64) return launch_cfg<TI, TO, 2, 2, 2, 2>(p, s);   // 128 x 128
     if (p.CO > 32) return launch_cfg<TI, TO, 2, 2, 2, 1>(p, s);   // 128 x 64
     return launch_cfg<TI, TO, 4, 1, 1, 1>(p, s);                  // 128 x 32
 }
 
 }  // namespace
+
+extern "C" NSG_API void nsg_debug_set_gather_tile8(int on) { g_gather_tile8 = on; }
 
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 {
