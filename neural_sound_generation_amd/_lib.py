@@ -114,6 +114,13 @@ def load():
         fn.restype = c_int32 if res is None else res
     if lib.nsg_version() < 100:
         raise NsgError("libnsg.so is older than this package")
+    # experiment switches (diagnostics): NSG_GATHER_DMA=0|1, NSG_GATHER_TILE8=0|1 select gather_gemm staging / tile variants
+    for env, sym in (("NSG_GATHER_DMA", "nsg_debug_set_gather_dma"), ("NSG_GATHER_TILE8", "nsg_debug_set_gather_tile8")):
+        if env in os.environ:
+            fn = getattr(lib, sym)
+            fn.argtypes = [c_int32]
+            fn.restype = None
+            fn(int(os.environ[env]))
     _lib = lib
     return lib
 

@@ -83,6 +83,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     sink[blockIdx.x * 256 + tid] = s;
 }
 
+// The same loop with the staging done by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without the VGPR -> LDS transfer).
+// A wave-instruction deposits 64 x 16 B contiguously, so rows are unpadded (128 B) and the fragment reads are XOR-swizzled
+// (piece ^= (row >> 1) & 7, with row & 1 selecting the bank half) to stay conflict-free.  src: any 64 KiB (L2-resident).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void lds_dma_loop_kernel(int chunks, const float *src, float *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][256 rows][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, 65536, 0x00020000);
+    v16f acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = tid; i < 2 * 256 * 32; i += 256) smem[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    const int ra0 = wr * 64 + l31, rb0 = 128 + wc * 64 + l31;
+    for (int it = 0; it < chunks; ++it) {
+        const int cur = it & 1;
+        const char *base = reinterpret_cast<const char *>(smem) + cur * 256 * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v4f a[2], b[2];
+            const int c = 2 * kk + h;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const int r = ra0 + 32 * i; a[i] = *reinterpret_cast<const v4f *>(base + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const int r = rb0 + 32 * j; b[j] = *reinterpret_cast<const v4f *>(base + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+        }
+        // 8 pieces per thread: wave w, piece j deposits rows 32 j + 8 w .. + 7 of the other buffer
+        char *dstb = reinterpret_cast<char *>(smem) + (cur ^ 1) * 256 * 128;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dstb + (32 * j + 8 * wave) * 128), 16,
+                                                     ((it * 8 + j) * 4096 + lane * 16) & 0xffff, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the DMA writes have landed
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    sink[blockIdx.x * 256 + tid] = s;
+}
+
 // The same with 8 waves on a 256 x 128 tile (one workgroup per CU, still two waves per SIMD, each wave 64 x 64): the weight
 // tile is staged once for twice the rows: 6 stores per thread per chunk instead of 8.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void lds_fed_loop8_kernel(int chunks, int mode, float *sink)
@@ -128,6 +174,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void l
 }  // namespace
 
 extern "C" {
+
+NSG_API int nsg_debug_lds_dma_loop(int32_t blocks, int32_t chunks, const float *src, float *sink, void *stream)
+{
+    NSG_REQUIRE(blocks > 0 && chunks > 0 && src && sink, NSG_E_INVALID, "nsg_debug_lds_dma_loop: bad argument");
+    const size_t lds = (size_t)2 * 256 * 32 * sizeof(float);
+    hipLaunchKernelGGL(lds_dma_loop_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, chunks, src, sink);
+    return nsg_check_launch("lds_dma_loop_kernel");
+}
 
 NSG_API int nsg_debug_lds_fed_loop8(int32_t blocks, int32_t chunks, int32_t mode, float *sink, void *stream)
 {

@@ -40,3 +40,18 @@ for mode, name in ((1, "256x128 tile, 8 waves: reads + barrier"), (0, "256x128 t
     t = a.elapsed_time(b) / 5 * 1e-3
     fl = 2.0 * 256 * 128 * 64 * chunks * 1280
     print(f"{name:50s} {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
+
+lib.nsg_debug_lds_dma_loop.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+src = torch.rand(16384, device="cuda:0")
+for _ in range(3):
+    lib.nsg_debug_lds_dma_loop(blocks, chunks, src.data_ptr(), sink.data_ptr(), st)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(5):
+    lib.nsg_debug_lds_dma_loop(blocks, chunks, src.data_ptr(), sink.data_ptr(), st)
+b.record()
+torch.cuda.synchronize()
+t = a.elapsed_time(b) / 5 * 1e-3
+fl = 2.0 * 128 * 128 * 64 * chunks * blocks
+print(f"{'128x128, staging by LDS-DMA (L2-resident source)':50s} {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TFLOP/s")
