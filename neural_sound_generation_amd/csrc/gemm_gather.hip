@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     static_assert(!DMA || (BM * CP + BM) <= STAGE_FLOATS, "the DMA ring must hold the output tile and the row offsets");
     float *Cs = smem;                         // epilogue: [BM][CP], reuses As/Bs
 
+    const unsigned long long st_entry = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostics
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         rbase[j] = 0;
         tapmask[j] = 0;
         if (m < p.M) {
-            const int b = m / (p.RH * p.RW);
+            const int b = nsg_div(m, p.div_rhw);            // launch-invariant divisors: multiply-shift, not the ~40-instruction division
             const int rem = m - b * (p.RH * p.RW);
-            const int ry = rem / p.RW;
+            const int ry = nsg_div(rem, p.div_rw);
             const int rx = rem - ry * p.RW;
             int iy0, ix0;
             if (MODE == 0) { iy0 = ry * p.stride - p.pad; ix0 = rx * p.stride - p.pad_w; }
@@ -150,9 +151,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         const int m = m0 + t;
         int off = -1;
         if (m < p.M) {
-            const int b = m / (p.RH * p.RW);
+            const int b = nsg_div(m, p.div_rhw);            // launch-invariant divisors: multiply-shift, not the ~40-instruction division
             const int rem = m - b * (p.RH * p.RW);
-            const int ry = rem / p.RW;
+            const int ry = nsg_div(rem, p.div_rw);
             const int rx = rem - ry * p.RW;
             const int oy = (MODE == 0) ? ry : 2 * ry + py;
             const int ox = (MODE == 0) ? rx : 2 * rx + px;
@@ -162,6 +163,16 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     }
     };
     if constexpr (!DMA) fill_rowoff();
+
+    // the epilogue's column group of this thread and its bias values: fetched now, the epilogue must not wait on them
+    constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
+    constexpr int NV = BN / EPO;                // 16-byte pieces per tile row; divides the thread count, so a thread keeps its columns
+    static_assert(NT % NV == 0, "a thread's column group must not change from row to row");
+    const int cq = (tid % NV) * EPO;
+    const int col = n0 + cq;
+    float bv[EPO];
+#pragma unroll
+    for (int e = 0; e < EPO; ++e) bv[e] = (p.bias && col + e < p.CO) ? p.bias[col + e] : 0.f;
 
     const int nchunks = (p.CI + KC - 1) / KC;
     const int nit = ntaps * nchunks;
@@ -359,8 +370,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     }
     if (p.stamps && tid == 0) {   // diagnostics: never read by any kernel
         const int sbid = blockIdx.y * gridDim.x + blockIdx.x;
-        p.stamps[2 * sbid] = __builtin_amdgcn_s_memtime() - st_t0;
-        p.stamps[2 * sbid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * sbid] = t1 - st_t0;                                   // main loop, shader cycles
+        p.stamps[4 * sbid + 1] = __builtin_amdgcn_s_memrealtime() - st_r0; // main loop, 100 MHz ticks
+        p.stamps[4 * sbid + 2] = st_t0 - st_entry;                         // prologue (index arithmetic), shader cycles
+        p.stamps[4 * sbid + 3] = t1;                                       // (epilogue = exit stamp - this; written below)
     }
     __syncthreads();   // everyone is done reading As/Bs: the region becomes the output staging tile
 
@@ -379,15 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     __syncthreads();
     const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
-    constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
     const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);
-    constexpr int NV = BN / EPO;     // 16-byte pieces per tile row; divides 256, so a thread keeps its columns
-    static_assert(NT % NV == 0, "a thread's column group must not change from row to row");
-    const int cq = (tid % NV) * EPO;
-    const int col = n0 + cq;
-    float bv[EPO];
-#pragma unroll
-    for (int e = 0; e < EPO; ++e) bv[e] = (p.bias && col + e < p.CO) ? p.bias[col + e] : 0.f;
     const bool full_vec = vec_store && col + EPO - 1 < p.CO;
     const TO *__restrict__ epi_add = reinterpret_cast<const TO *>(p.epi_add);     // (launcher: only with full 16-byte pieces)
     const TO *__restrict__ epi_mask = reinterpret_cast<const TO *>(p.epi_mask);
@@ -508,6 +514,13 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             dst[2 * p.CO + colg] = fmaxf(t2 - t1 * t1 * inv, 0.f);  // sum of squares about the tile mean
         }
     }
+    if (p.stamps) {   // diagnostics: epilogue cycles of this workgroup (all its stores issued)
+        __syncthreads();
+        if (tid == 0) {
+            const int sbid = blockIdx.y * gridDim.x + blockIdx.x;
+            p.stamps[4 * sbid + 3] = __builtin_amdgcn_s_memtime() - p.stamps[4 * sbid + 3];
+        }
+    }
 }
 
 template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU, bool DMA = false>
@@ -604,6 +617,8 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
     }
     p.in_bytes = (unsigned)in_bytes;
     p.w_bytes = (unsigned)w_bytes;
+    p.div_rw = nsg_fastdiv((uint32_t)p.RW);
+    p.div_rhw = nsg_fastdiv((uint32_t)p.RH * (uint32_t)p.RW);
     if (p.CI % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of %d", p.CI, epv);
     if (!nsg_aligned16(p.in) || !nsg_aligned16(p.w)) return nsg_fail(NSG_E_INVALID, "gather_gemm: operands must be 16-byte aligned");
     if (p.in_dtype == NSG_F32 && p.out_dtype == NSG_F32) return launch_typed<float, float>(p, s);

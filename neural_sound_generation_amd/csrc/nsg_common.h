@@ -166,6 +166,7 @@ struct GatherGemmParams {
     int flags;   // NSG_RELU_IN | NSG_TANH_OUT
     const void *epi_add;   // optional, laid out like `out` (elements of out_dtype): out = acc + bias + epi_add ...
     const void *epi_mask;  // optional, laid out like `out`: ... then zeroed where epi_mask <= 0 (gradient through a ReLU)
+    FastDiv div_rw, div_rhw;     // division by RW and by RH*RW (filled in by nsg_launch_gather_gemm)
     unsigned in_bytes, w_bytes;  // sizes of `in` and `w` (filled in by nsg_launch_gather_gemm; buffer-load range checks)
     unsigned long long *stamps;  // diagnostics only: per block (shader cycles, 100 MHz ticks) spent in the main loop
     float *stats;  // optional [n_row_tiles][3][CO]: per row tile (valid-row count, mean, M2 about it) of the OUTPUT

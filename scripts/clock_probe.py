@@ -33,14 +33,14 @@ for name, (k, s_, p_, tr, ih, iw) in {"3x3": (3, 1, 1, False, 20, 256), "4x4s2":
     x = torch.randn(B, ih, iw, D, device=dev); w = torch.randn(D, D, k, k, device=dev) * 0.05
     wf, _ = ops.pack_weights(d, w); bias = torch.zeros(D, device=dev)
     nblk = (B * d.OH * d.OW + 127) // 128
-    stamps = torch.zeros(nblk * 2, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
     for _ in range(3):
         ops.conv_forward(d, x, wf, bias, flags=ops.NSG_RELU_IN)
     lib.nsg_debug_set_stamp_buffer(stamps.data_ptr())
     ops.conv_forward(d, x, wf, bias, flags=ops.NSG_RELU_IN)
     torch.cuda.synchronize()
     lib.nsg_debug_set_stamp_buffer(None)
-    s = stamps.cpu().numpy().reshape(-1, 2).astype(np.float64)
+    s = stamps.cpu().numpy().reshape(-1, 4).astype(np.float64)
     clk = np.median(s[:, 0] / np.maximum(s[:, 1], 1)) * 100e6
     nit = k * k * (D // 32)
     ideal = nit * 64 * 64          # cycles of MFMA work per wave (64 MFMAs x 64 cycles per chunk)
