@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]),
                                                                            acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][q], a[i][q], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -378,19 +378,26 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     }
     __syncthreads();   // everyone is done reading As/Bs: the region becomes the output staging tile
 
-    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue.  The MFMAs were issued with the operands swapped (weights as A, pixels as B), so an accumulator tile is
+    //      the TRANSPOSED output tile: in the 32x32 C/D layout (column = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    //      the column is the pixel and the rows are output channels -- each lane holds 4 CONSECUTIVE channels of its pixel per
+    //      register group, i.e. 16-byte LDS writes (16 per thread instead of 64 scalar ones).  Same products, same order. ----
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = wc * TN * 32 + j * 32 + l31;
+    for (int i = 0; i < TM; ++i) {
+        const int row = wr * TM * 32 + i * 32 + l31;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Cs[row * CP + col] = acc[i][j][r];
+            for (int g = 0; g < 4; ++g) {
+                const int col = wc * TN * 32 + j * 32 + 8 * g + 4 * h;
+                *reinterpret_cast<v4f *>(Cs + row * CP + col) = v4f{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
             }
     }
     __syncthreads();
+    if (p.stamps && tid == 0) {   // diagnostics: cycles from the last MFMA issue to the output tile standing in LDS
+        const int sbid = blockIdx.y * gridDim.x + blockIdx.x;
+        p.stamps[4 * sbid + 1] = __builtin_amdgcn_s_memtime() - p.stamps[4 * sbid + 3];
+    }
     const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
     const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);

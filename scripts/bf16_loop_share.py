@@ -28,11 +28,11 @@ for name, (k, s_, p_, ih, iw) in {"3x3": (3, 1, 1, 20, 256), "4x4s2": (4, 2, 1, 
     torch.cuda.synchronize()
     lib.nsg_debug_set_stamp_buffer(None)
     s = stamps.cpu().numpy().reshape(-1, 4).astype(np.float64)
-    clk = np.median(s[:, 0] / np.maximum(s[:, 1], 1)) * 100e6
+    clk = 1.9e9   # (the realtime stamp slot now carries the epilogue split)
     t = a.elapsed_time(b) * 1e-3
     rounds = nblk / 512.0
     per_block_total = t / rounds * clk            # cycles a resident workgroup lives if the kernel were perfectly round-structured
     nit = k * k * (D // 64)
     print(f"{name}: kernel {t * 1e6:.1f} us, clock {clk / 1e9:.2f} GHz, {nblk} workgroups = {rounds:.1f} rounds of 512; main loop {np.median(s[:, 0]):.0f} cycles "
           f"median ({nit} chunks -> {np.median(s[:, 0]) / nit:.0f} per chunk; MFMA-only for the SIMD's two waves {2 * nit * 16 * 32}); a workgroup's slot lasts ~{per_block_total:.0f} cycles "
-          f"-> main loop share {np.median(s[:, 0]) / per_block_total:.2f}; prologue {np.median(s[:, 2]):.0f}, epilogue {np.median(s[:, 3]):.0f} cycles")
+          f"-> main loop share {np.median(s[:, 0]) / per_block_total:.2f}; prologue {np.median(s[:, 2]):.0f}, epilogue {np.median(s[:, 3]):.0f} cycles (of which until the tile stands in LDS: {np.median(s[:, 1]):.0f})")
