@@ -398,6 +398,60 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         const int sbid = blockIdx.y * gridDim.x + blockIdx.x;
         p.stamps[4 * sbid + 1] = __builtin_amdgcn_s_memtime() - p.stamps[4 * sbid + 3];
     }
+    // ---- optional: BatchNorm batch statistics of this output tile, merged across tiles by
+    //      bn_stats_from_tiles -- saves a full read pass over the conv output.  One LDS pass: sums of
+    //      (v - pivot) and (v - pivot)^2 with pivot = the tile's first row (a sample of the column, so
+    //      no cancellation); written as (count, sum v, sum (v - mean_tile)^2).  Done BEFORE the output stores: its barrier
+    //      would otherwise wait for every store of the tile to be acknowledged (vmcnt(0)) ----
+    if constexpr (NT == 256) if (p.stats != nullptr) {
+        constexpr int PARTS = 256 / BN;          // threads per column
+        constexpr int RPP = BM / PARTS;          // rows per part
+        float *red = smem + BM * CP;             // [2][256] scratch behind the staging tile
+        const int colw = tid % BN, part = tid / BN;
+        const bool all_valid = (MODE == 0) ? (m0 + BM <= p.M) : false;   // conv-mode interior tile: every row is real
+        const float pivot = Cs[colw];            // row 0 of the tile (always a real row when the tile has any)
+        float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+        if (all_valid) {
+#pragma unroll 8
+            for (int r = part * RPP; r < (part + 1) * RPP; ++r) {
+                const float dlt = Cs[r * CP + colw] - pivot;
+                s1 += dlt;
+                s2 += dlt * dlt;
+            }
+            cnt = (float)RPP;
+        } else {
+            for (int r = part * RPP; r < (part + 1) * RPP; ++r)
+                if (rowoff[r] >= 0) {
+                    const float dlt = Cs[r * CP + colw] - pivot;
+                    s1 += dlt;
+                    s2 += dlt * dlt;
+                    cnt += 1.f;
+                }
+        }
+        red[tid] = s1;
+        red[256 + tid] = s2;
+        __syncthreads();
+        const int colg = n0 + colw;
+        if (part == 0 && colg < p.CO) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) { t1 += red[q * BN + colw]; t2 += red[256 + q * BN + colw]; }
+            float tcnt = cnt;
+            if (!all_valid) {   // counts differ per part only in edge tiles: recount exactly
+                tcnt = 0.f;
+                for (int r = 0; r < BM; ++r) tcnt += rowoff[r] >= 0 ? 1.f : 0.f;
+            } else {
+                tcnt = (float)BM;
+            }
+            const int ntm = gridDim.x / ntiles_n;
+            float *dst = p.stats + (size_t)(cls * ntm + mtile) * 3 * p.CO;
+            const float bv = p.bias ? p.bias[colg] : 0.f;
+            const float inv = tcnt > 0.f ? 1.f / tcnt : 0.f;
+            dst[colg] = tcnt;
+            dst[p.CO + colg] = tcnt * (pivot + bv) + t1;            // sum of the (biased) outputs over the tile's rows
+            dst[2 * p.CO + colg] = fmaxf(t2 - t1 * t1 * inv, 0.f);  // sum of squares about the tile mean
+        }
+    }
     const bool tanh_out = (p.flags & NSG_TANH_OUT) != 0;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
     const bool vec_store = ((p.CO % EPO) == 0) && nsg_aligned16_dev(p.out);
@@ -468,59 +522,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         }
     }
 
-    // ---- optional: BatchNorm batch statistics of this output tile, merged across tiles by
-    //      bn_stats_from_tiles -- saves a full read pass over the conv output.  One LDS pass: sums of
-    //      (v - pivot) and (v - pivot)^2 with pivot = the tile's first row (a sample of the column, so
-    //      no cancellation); written as (count, sum v, sum (v - mean_tile)^2) ----
-    if constexpr (NT == 256) if (p.stats != nullptr) {
-        constexpr int PARTS = 256 / BN;          // threads per column
-        constexpr int RPP = BM / PARTS;          // rows per part
-        float *red = smem + BM * CP;             // [2][256] scratch behind the staging tile
-        const int colw = tid % BN, part = tid / BN;
-        const bool all_valid = (MODE == 0) ? (m0 + BM <= p.M) : false;   // conv-mode interior tile: every row is real
-        const float pivot = Cs[colw];            // row 0 of the tile (always a real row when the tile has any)
-        float s1 = 0.f, s2 = 0.f, cnt = 0.f;
-        if (all_valid) {
-#pragma unroll 8
-            for (int r = part * RPP; r < (part + 1) * RPP; ++r) {
-                const float dlt = Cs[r * CP + colw] - pivot;
-                s1 += dlt;
-                s2 += dlt * dlt;
-            }
-            cnt = (float)RPP;
-        } else {
-            for (int r = part * RPP; r < (part + 1) * RPP; ++r)
-                if (rowoff[r] >= 0) {
-                    const float dlt = Cs[r * CP + colw] - pivot;
-                    s1 += dlt;
-                    s2 += dlt * dlt;
-                    cnt += 1.f;
-                }
-        }
-        red[tid] = s1;
-        red[256 + tid] = s2;
-        __syncthreads();
-        const int colg = n0 + colw;
-        if (part == 0 && colg < p.CO) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < PARTS; ++q) { t1 += red[q * BN + colw]; t2 += red[256 + q * BN + colw]; }
-            float tcnt = cnt;
-            if (!all_valid) {   // counts differ per part only in edge tiles: recount exactly
-                tcnt = 0.f;
-                for (int r = 0; r < BM; ++r) tcnt += rowoff[r] >= 0 ? 1.f : 0.f;
-            } else {
-                tcnt = (float)BM;
-            }
-            const int ntm = gridDim.x / ntiles_n;
-            float *dst = p.stats + (size_t)(cls * ntm + mtile) * 3 * p.CO;
-            const float bv = p.bias ? p.bias[colg] : 0.f;
-            const float inv = tcnt > 0.f ? 1.f / tcnt : 0.f;
-            dst[colg] = tcnt;
-            dst[p.CO + colg] = tcnt * (pivot + bv) + t1;            // sum of the (biased) outputs over the tile's rows
-            dst[2 * p.CO + colg] = fmaxf(t2 - t1 * t1 * inv, 0.f);  // sum of squares about the tile mean
-        }
-    }
     if (p.stamps) {   // diagnostics: epilogue cycles of this workgroup (all its stores issued)
         __syncthreads();
         if (tid == 0) {
