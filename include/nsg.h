@@ -242,6 +242,32 @@ NSG_API int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, c
                             size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The single-channel input layer with its BatchNorm, as one operator     src/models.py:165-167
+ *   encoder.0 Conv2d(1, C, 4, 2, 1) -> encoder.1 BatchNorm2d(C) -> encoder.2 ReLU(True)
+ * The convolution's output is 2C times larger than the image it comes from and costs 16 multiply-adds
+ * per element, so it is never stored: the statistics pass, the apply pass and both backward passes
+ * recompute it from the image (one tensor write forward, two tensor reads backward, against three
+ * writes and eight reads of nsg_conv_forward + nsg_bn_stats + nsg_bn_apply + nsg_bn_backward +
+ * nsg_conv_wgrad, whose results these reproduce: same value for h bit for bit, same expressions).
+ *   img [B][H][W] fp32 (H, W even); w the parameter's own layout (C,1,4,4) = [C][16] fp32; bias [C] or NULL;
+ *   y / dy [B][H/2][W/2][C] of y_dtype / dy_dtype (NSG_F32 or NSG_BF16); C % 4 == 0, C <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+NSG_API size_t nsg_c1conv_bn_workspace_bytes(int32_t C);
+/* training != 0: mean / invstd [C] are OUTPUTS (batch statistics of the conv output; running_mean / running_var
+ * updated with `momentum` when not NULL, unbiased variance as nn.BatchNorm2d); training == 0: they are INPUTS
+ * (nsg_bn_eval_stats) and the workspace is not used.  y = max(0, (h - mean) * (invstd * gamma) + beta). */
+NSG_API int nsg_c1conv_bn_relu_forward(const float *img, const float *w, const float *bias, const float *gamma, const float *beta,
+                                       float *mean, float *invstd, float *running_mean, float *running_var, float eps,
+                                       float momentum, int32_t training, void *y, int32_t y_dtype, int32_t B, int32_t H,
+                                       int32_t W, int32_t C, void *workspace, size_t workspace_bytes, void *stream);
+/* Gradients of the layer's parameters from dy = dL/dy (the image is data: no input gradient):
+ * dw [C][16], dbias [C] or NULL, dgamma [C], dbeta [C], all overwritten; mean / invstd as the forward left them. */
+NSG_API int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const float *bias, const float *gamma,
+                                        const float *beta, const float *mean, const float *invstd, const void *dy,
+                                        int32_t dy_dtype, float *dw, float *dbias, float *dgamma, float *dbeta, int32_t B,
+                                        int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Element-wise, losses, optimiser                         src/train.py:118-136
  * ------------------------------------------------------------------------------------------- */
 

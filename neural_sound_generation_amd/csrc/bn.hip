@@ -435,6 +435,13 @@ int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, fl
     return nsg_check_launch("bn_stats_from_tiles");
 }
 
+int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s)
+{
+    if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "bn_bwd_final: %d slabs / %d channels not supported", nslab, C);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, nslab, C, dgamma, dbeta);
+    return nsg_check_launch("bn_bwd_final_kernel");
+}
+
 extern "C" {
 
 size_t nsg_bn_workspace_bytes(int64_t M, int32_t C)

@@ -200,3 +200,5 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
 
 int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, float eps, float momentum, float *mean,
                             float *invstd, float *running_mean, float *running_var, hipStream_t s);
+// dbeta[c] = sum_s partial[s][0][c], dgamma[c] = sum_s partial[s][1][c] over nslab <= 1024 slabs of [2][C] (fixed order, double)
+int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s);

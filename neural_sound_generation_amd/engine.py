@@ -68,6 +68,10 @@ class DecoderParams:
 # path while the stand-alone pass streams at 5 TB/s -- so the separate pass is the default.
 import os as _os
 FUSED_BN_STATS = _os.environ.get("NSG_FUSED_BN_STATS", "0") == "1"
+# encoder.0-2 (Conv2d(1, D, 4, 2, 1) -> BatchNorm -> ReLU) as one operator that never stores the conv output
+# (ops.c1conv_bn_relu_*): measured on MI355X, bf16, B=128: see DESIGN.md section 3.  NSG_FUSED_C1_LAYER=0 restores
+# the four separate operators (same values: the fused passes recompute the conv output bit for bit).
+FUSED_C1_LAYER = _os.environ.get("NSG_FUSED_C1_LAYER", "1") == "1"
 
 
 # num_batches_tracked += 1 per BatchNorm is ten tiny launches a step; a fused step collects the counters here
@@ -179,8 +183,19 @@ def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32, pa
     d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1, dtype=dtype)
     pk = packs if packs is not None else {}
     wf0, _ = pk["conv0"] if packs is not None else ops.pack_weights(d0, P.conv0.weight, want_dgrad=False)
-    h0, m0, i0 = _conv_bn(d0, x, wf0, P.conv0, P.bn0, training)
-    a0 = ops.bn_apply(h0, m0, i0, P.bn0.weight, P.bn0.bias, relu=True)
+    if FUSED_C1_LAYER and D % 4 == 0 and D <= 1024 and H % 2 == 0 and W % 2 == 0:
+        h0 = None                                    # never materialised; the backward recomputes it from x
+        if training:
+            a0, m0, i0 = ops.c1conv_bn_relu_forward(x, P.conv0.weight, P.conv0.bias, P.bn0.weight, P.bn0.bias, P.bn0.running_mean,
+                                                    P.bn0.running_var, training=True, out_dtype=dtype)
+            _bump(P.bn0)
+        else:
+            m0, i0 = ops.bn_eval_stats(P.bn0.running_mean, P.bn0.running_var)
+            a0, _, _ = ops.c1conv_bn_relu_forward(x, P.conv0.weight, P.conv0.bias, P.bn0.weight, P.bn0.bias, training=False,
+                                                  mean=m0, invstd=i0, out_dtype=dtype)
+    else:
+        h0, m0, i0 = _conv_bn(d0, x, wf0, P.conv0, P.bn0, training)
+        a0 = ops.bn_apply(h0, m0, i0, P.bn0.weight, P.bn0.bias, relu=True)
     d3 = ops.conv_desc(B, d0.OH, d0.OW, D, D, 4, 2, 1, dtype=dtype)
     wf3, wd3 = pk["conv3"] if packs is not None else ops.pack_weights(d3, P.conv3.weight)
     e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias, flags=NSG_RELU_OUT)     # stored ReLU'd: its only consumer is a ResBlock
@@ -200,6 +215,10 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
     de3, g4 = resblock_backward(dr4, s4, P.res4, gout=o[6:14] if gout is not None else None)
     dw3, db3 = ops.conv_wgrad(d3, a0, de3, P.conv3.weight.shape, dw=o[4], dbias=o[5])
     da0 = ops.conv_dgrad(d3, de3, wd3)
+    if h0 is None:      # fused input layer: BatchNorm backward and the weight gradient straight from (x, da0)
+        dw0, db0, dg0, dbe0 = ops.c1conv_bn_relu_backward(x, P.conv0.weight, P.conv0.bias, P.bn0.weight, P.bn0.bias, m0, i0, da0,
+                                                          dw=o[0], dbias=o[1], dgamma=o[2], dbeta=o[3])
+        return [dw0, db0, dg0, dbe0, dw3, db3] + g4 + g5
     db0 = o[1] if o[1] is not None else torch.empty(h0.shape[-1], dtype=torch.float32, device=h0.device)
     dh0, dg0, dbe0 = ops.bn_backward(h0, None, da0, m0, i0, P.bn0.weight, dgamma=o[2], dbeta=o[3], dx_colsum=db0, relu_beta=P.bn0.bias)
     dw0, _ = ops.conv_wgrad(d0, x, dh0, P.conv0.weight.shape, dw=o[0], want_bias=False)

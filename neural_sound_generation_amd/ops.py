@@ -368,6 +368,53 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
 
 
 # ------------------------------------------------------------------------------------------------
+# encoder.0-2 as one operator: Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU   (src/models.py:165-167)
+# ------------------------------------------------------------------------------------------------
+def c1conv_bn_relu_forward(img, w, bias, gamma, beta, running_mean=None, running_var=None, training=True, eps=1e-5, momentum=0.1,
+                           mean=None, invstd=None, out_dtype=torch.float32):
+    """img fp32 (B, H, W) or (B, H, W, 1); w the Conv2d parameter (C, 1, 4, 4) fp32.  Returns (y NHWC (B, H/2, W/2, C) of
+    out_dtype, mean, invstd).  training=False: mean / invstd must be given (bn_eval_stats).  The conv output itself is
+    never stored (nsg.h: nsg_c1conv_bn_relu_forward)."""
+    _chk(img, "img", torch.float32); _chk(w, "w", torch.float32)
+    B, H, W = img.shape[0], img.shape[1], img.shape[2]
+    C = w.shape[0]
+    if w.numel() != C * 16 or img.numel() != B * H * W:
+        raise ValueError("c1conv_bn_relu_forward: img must be single-channel and w (C, 1, 4, 4)")
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=img.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=img.device)
+    elif mean is None or invstd is None:
+        raise ValueError("c1conv_bn_relu_forward: eval mode needs mean and invstd")
+    y = torch.empty((B, H // 2, W // 2, C), dtype=out_dtype, device=img.device)
+    nb = _lib.query("nsg_c1conv_bn_workspace_bytes", c_int32(C))
+    ws = WS.get(nb, img.device)
+    _lib.call("nsg_c1conv_bn_relu_forward", _p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(running_mean),
+              _p(running_var), c_float(eps), c_float(momentum), c_int32(1 if training else 0), _p(y), c_int32(nsg_dtype(out_dtype)),
+              c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws), c_size_t(nb), _stream())
+    return y, mean, invstd
+
+
+def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None, dbias=None, dgamma=None, dbeta=None):
+    """Parameter gradients (dw (C, 1, 4, 4), dbias, dgamma, dbeta) of the fused layer from dy (B, H/2, W/2, C)."""
+    _chk(img, "img", torch.float32); _chk(w, "w", torch.float32); _chk(dy, "dy", None)
+    B, H, W = img.shape[0], img.shape[1], img.shape[2]
+    C = w.shape[0]
+    if dy.numel() != B * (H // 2) * (W // 2) * C:
+        raise ValueError("c1conv_bn_relu_backward: dy does not match (B, H/2, W/2, C)")
+    dev = img.device
+    dw = dw if dw is not None else torch.empty_like(w)
+    dbias = dbias if dbias is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    dgamma = dgamma if dgamma is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    nb = _lib.query("nsg_c1conv_bn_workspace_bytes", c_int32(C))
+    ws = WS.get(nb, dev)
+    _lib.call("nsg_c1conv_bn_relu_backward", _p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dy),
+              c_int32(nsg_dtype(dy.dtype)), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C),
+              _p(ws), c_size_t(nb), _stream())
+    return dw, dbias, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
 # element-wise / losses / optimiser
 # ------------------------------------------------------------------------------------------------
 def relu_backward_add(a, b, x, out=None):

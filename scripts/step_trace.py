@@ -1,5 +1,7 @@
 """Per-dispatch listing of ONE training step from a rocprofv3 --kernel-trace CSV (the step between the last two
-adam_kernel dispatches): start offset, duration, kernel, blocks.  Usage: python scripts/step_trace.py <kernel_trace.csv>"""
+adam_kernel dispatches, or the last such step containing a kernel whose name has the optional substring -- e.g.
+"gather_gemm_kernel<unsigned short" for the bf16 step of a bench run that also times fp32): start offset, duration, kernel,
+blocks.  Usage: python scripts/step_trace.py <kernel_trace.csv> [substring]"""
 import csv
 import sys
 
@@ -7,6 +9,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
 a, b = idx[-2] + 1, idx[-1] + 1
+if len(sys.argv) > 2:
+    for k in range(len(idx) - 1, 0, -1):
+        if any(sys.argv[2] in r["Kernel_Name"] for r in rows[idx[k - 1] + 1:idx[k] + 1]):
+            a, b = idx[k - 1] + 1, idx[k] + 1
+            break
 t0 = int(rows[a]["Start_Timestamp"])
 tot = 0.0
 agg = {}

@@ -464,6 +464,61 @@ def test_batchnorm_train_forward_backward(B, C, H, W, relu, res):
     _close(dbg.cpu(), gb, tol=3e-5, what="bn dbeta")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 80, 64, 128), (2, 20, 260, 48), (1, 6, 130, 256), (2, 4, 4, 4)])
+@pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16"])
+def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
+    """encoder.0-2 (Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU, src/models.py:165-167) as one operator whose conv output is
+    never stored: against CPU PyTorch autograd (1e-5 forward, 3e-5 gradients, relative to the largest reference value) and
+    against the unfused operators of this library (fp32: the same conv values bit for bit, so the same mask and results
+    to rounding of the statistics' summation order)."""
+    g = torch.Generator().manual_seed(B * 1000 + C + W)
+    img = torch.randn(B, 1, H, W, generator=g) * 0.7 + 0.3
+    w = (torch.randn(C, 1, 4, 4, generator=g) * 0.3).requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.relu(F.batch_norm(F.conv2d(img, w, b, 2, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    dy = torch.randn(y.shape, generator=g)
+    gw, gb, gg, gbe = torch.autograd.grad(y, [w, b, gamma, beta], dy)
+
+    dt = torch.bfloat16 if bf else torch.float32
+    imgg = gpu(img.view(B, H, W))
+    wg, bg, gag, beg = gpu(w.detach()), gpu(b.detach()), gpu(gamma.detach()), gpu(beta.detach())
+    rmg, rvg = gpu(rm), gpu(rv)
+    yg, mean, invstd = ops.c1conv_bn_relu_forward(imgg, wg, bg, gag, beg, rmg, rvg, training=True, out_dtype=dt)
+    np.testing.assert_allclose(rmg.cpu().numpy(), rm_ref.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvg.cpu().numpy(), rv_ref.numpy(), rtol=1e-5, atol=1e-6)
+    _close(nchw(yg.float().cpu()), y.detach(), tol=1e-2 if bf else 1e-5, what="fused layer forward")
+    dyg = gpu(nhwc(dy)).to(dt)
+    dw, dbias, dgm, dbt = ops.c1conv_bn_relu_backward(imgg, wg, bg, gag, beg, mean, invstd, dyg)
+    tol = 1e-2 if bf else 3e-5           # bf16: dy itself is rounded to 8 bits
+    _close(dw.cpu(), gw, tol=tol, what="fused layer dw")
+    _close(dgm.cpu(), gg, tol=tol, what="fused layer dgamma")
+    _close(dbt.cpu(), gbe, tol=tol, what="fused layer dbeta")
+    # the conv bias sits in front of a BatchNorm: its true gradient is zero up to rounding
+    assert float(dbias.abs().max()) <= 1e-4 * float(dyg.float().abs().sum(dim=(0, 1, 2)).max()) + 1e-6
+
+    # eval mode: statistics are inputs
+    em, ei = ops.bn_eval_stats(rmg, rvg)
+    ye, _, _ = ops.c1conv_bn_relu_forward(imgg, wg, bg, gag, beg, training=False, mean=em, invstd=ei, out_dtype=dt)
+    y_eval = F.relu(F.batch_norm(F.conv2d(img, w, b, 2, 1), rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-5)).detach()
+    _close(nchw(ye.float().cpu()), y_eval, tol=1e-2 if bf else 1e-5, what="fused layer eval forward")
+
+    if not bf:   # against the unfused chain of this library, given the SAME statistics: identical values
+        d = ops.conv_desc(B, H, W, 1, C, 4, 2, 1)
+        wf, _ = ops.pack_weights(d, wg, want_dgrad=False)
+        h = ops.conv_forward(d, imgg.view(B, H, W, 1), wf, bg)
+        a = ops.bn_apply(h, mean, invstd, gag, beg, relu=True)
+        assert torch.equal(a, yg), "recomputed conv values differ from the stored ones"
+        dh, dg2, db2 = ops.bn_backward(h, None, dyg, mean, invstd, gag, relu_beta=beg)
+        _close(dgm.cpu(), dg2.cpu(), tol=1e-5, what="dgamma vs unfused")
+        _close(dbt.cpu(), db2.cpu(), tol=1e-5, what="dbeta vs unfused")
+        dw2, _ = ops.conv_wgrad(d, imgg.view(B, H, W, 1), dh, (C, 1, 4, 4), want_bias=False)
+        _close(dw.cpu(), dw2.cpu(), tol=2e-5, what="dw vs unfused")
+
+
 def test_batchnorm_eval():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 16, 6, 5, generator=g)
