@@ -1,0 +1,525 @@
+// The fused input layer Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU (src/models.py:165-167; C ABI nsg_c1conv_bn_relu_*)
+// in the throughput (bf16 storage) mode, with the convolution on the matrix cores.
+//
+// stencil_c1.hip's passes recompute the conv output h on the vector ALU: 16 multiply-adds per element, which makes every
+// pass ALU-bound (190 us for the 335M elements of the headline shape even with no tensor traffic at all).  Here a
+// 32-pixel x 32-channel block of h is ONE v_mfma_f32_32x32x16_bf16 -- the 16 taps are exactly its K -- issued three
+// times on (hi, lo) bf16 splits of the fp32 patch values and weights (lo*hi + hi*lo + hi*hi, fp32 accumulate: h to
+// ~2^-17 relative, far inside the bf16 storage of everything downstream), so the vector ALU only does the per-element
+// BatchNorm arithmetic and the passes run at the speed of their one tensor stream.
+//
+// Layout: block = NW waves, wave w owns channels 32w .. 32w+31 (C = 32 NW <= 128).  A tile is TW = 64 pixels of one row
+// = two pixel blocks.  MFMA operands: A = patch [pixel][tap], B = weights [tap][channel]; in the result a LANE IS A
+// CHANNEL (column = lane & 31) and its 16 registers are pixels (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the block, so
+//   * every per-channel constant is one register and every per-channel sum accumulates in-lane;
+//   * the gradient block d [pixel][channel] is directly the B operand [K = pixel][N = channel] of the weight-gradient
+//     MFMA  dw^T[tap][channel] += patch^T[tap][pixel] * d[pixel][channel]  (bf16 operands, as every weight gradient of
+//     this mode);
+//   * the tensor tile (dy in, y out) crosses between this layout and 16-byte global accesses through LDS.
+// All four passes build h with the same instruction sequence, so the ReLU decision of the forward is reproduced exactly
+// by the backward.  Expressions (per channel, fs = invstd*gamma, off = beta - mean*fs):
+//   t = fma(h, fs, off);  y = max(t, 0);  g = t > 0 ? dy : 0;
+//   sums:  sum g,  sum g*(h - mean)   (x invstd at the end);
+//   dh = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) = fma(sc, g, -fma(k1, h, k0)),
+//        sc = gamma*invstd, k1 = sc*invstd*dgamma/M, k0 = sc*dbeta/M - k1*mean.
+#include "nsg_common.h"
+#include "c1_geom.h"
+#include <type_traits>
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int NT> struct PatchRegs { static constexpr int N = (PATCH_VALS + NT - 1) / NT; };
+
+template <int NT>
+__device__ __forceinline__ void patch_load(float (&r)[PatchRegs<NT>::N], const float *__restrict__ img, const C1Geom &g, int b, int ly, int ox0, int tid)
+{
+    constexpr int NCOL = 2 * TW + 2;
+#pragma unroll
+    for (int q = 0; q < PatchRegs<NT>::N; ++q) {
+        const int i = tid + NT * q;
+        const int rr = i / NCOL, cix = i - rr * NCOL;
+        const int y = 2 * ly - 1 + rr, x = 2 * ox0 - 1 + cix;
+        const bool ok = (i < PATCH_VALS) & (y >= 0) & (y < g.HH) & (x >= 0) & (x < g.WW);
+        const float v = img[ok ? ((size_t)b * g.HH + y) * g.WW + x : 0];     // clamped, unconditional
+        r[q] = ok ? v : 0.f;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void patch_store(float *patch, const float (&r)[PatchRegs<NT>::N], int tid)
+{
+    constexpr int NCOL = 2 * TW + 2;
+#pragma unroll
+    for (int q = 0; q < PatchRegs<NT>::N; ++q) {
+        const int i = tid + NT * q;
+        if (i < PATCH_VALS) {
+            const int rr = i / NCOL, cix = i - rr * NCOL;
+            patch[rr * PP + cix] = r[q];
+        }
+    }
+}
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// two floats -> two bf16 in one register (one v_cvt_pk_bf16_f32, round to nearest even): a in the low half
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const v2f f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo)
+{
+    v4u h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned hp = pack_bf16(v[2 * i], v[2 * i + 1]);
+        h[i] = hp;
+        l[i] = pack_bf16(v[2 * i] - nsg_bitsf(hp << 16), v[2 * i + 1] - nsg_bitsf(hp & 0xffff0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// The wave's share of the conv weights as the MFMA B operand: lane (n, hb) holds taps 8hb .. 8hb+7 of channel c
+__device__ __forceinline__ void load_w_operand(const float *__restrict__ w, int c, int hb, bf16x8 &whi, bf16x8 &wlo)
+{
+    const v4f a = *reinterpret_cast<const v4f *>(w + (size_t)c * 16 + 8 * hb);
+    const v4f b = *reinterpret_cast<const v4f *>(w + (size_t)c * 16 + 8 * hb + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    split8(v, whi, wlo);
+}
+
+// h of pixel block mb (32 pixels) x the wave's 32 channels.  A operand: lane (m, hb) holds taps 8hb .. 8hb+7 of pixel
+// j = 32 mb + m, i.e. patch rows 2hb, 2hb+1, columns 2j .. 2j+3.
+__device__ __forceinline__ v16f conv_block(const float *patch, int mb, int lane, const bf16x8 whi, const bf16x8 wlo, float bias)
+{
+    const int m = lane & 31, hb = lane >> 5;
+    const float *p0 = patch + (2 * hb) * PP + 2 * (32 * mb + m);
+    const v2f a = *reinterpret_cast<const v2f *>(p0), b = *reinterpret_cast<const v2f *>(p0 + 2);
+    const v2f c = *reinterpret_cast<const v2f *>(p0 + PP), d = *reinterpret_cast<const v2f *>(p0 + PP + 2);
+    const float v[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    bf16x8 ahi, alo;
+    split8(v, ahi, alo);
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi, acc, 0, 0, 0);   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += bias;
+    return acc;
+}
+
+// pixel (within its 32-pixel block) of accumulator register r of a lane in half hb
+__device__ __forceinline__ int acc_pixel(int r, int hb) { return (r & 3) + 8 * (r >> 2) + 4 * hb; }
+
+constexpr int gpitch(int C) { return C + 8; }   // bf16 elements per LDS row of a tensor tile: rows 4 apart land 16 banks apart
+
+// ---- tensor tile (64 pixels x C channels, bf16) between global memory (16-byte pieces) and LDS ----
+// NT = 2C threads: 8C pieces of 16 bytes = 4 per thread.
+template <int NW>
+__device__ __forceinline__ void gtile_load(v4f (&r)[4], const bf16_t *__restrict__ t, const C1Geom &g, int b, int ly, int ox0, int npx, int tid)
+{
+    constexpr int C = 32 * NW, NT = 64 * NW, CPR = C / 8;    // pieces per row
+    const bf16_t *base = t + (((size_t)b * g.LH + ly) * g.LW + ox0) * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + NT * i;
+        const int row = q / CPR, cc = q - row * CPR;
+        r[i] = *reinterpret_cast<const v4f *>(base + (size_t)(row < npx ? row : 0) * C + 8 * cc);   // clamped: always inside the tensor
+    }
+}
+template <int NW>
+__device__ __forceinline__ void gtile_to_lds(bf16_t *buf, const v4f (&r)[4], int tid)
+{
+    constexpr int C = 32 * NW, NT = 64 * NW, CPR = C / 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + NT * i;
+        const int row = q / CPR, cc = q - row * CPR;
+        *reinterpret_cast<v4f *>(buf + row * gpitch(C) + 8 * cc) = r[i];
+    }
+}
+template <int NW>
+__device__ __forceinline__ void gtile_store(bf16_t *__restrict__ t, const bf16_t *buf, const C1Geom &g, int b, int ly, int ox0, int npx, int tid)
+{
+    constexpr int C = 32 * NW, NT = 64 * NW, CPR = C / 8;
+    bf16_t *base = t + (((size_t)b * g.LH + ly) * g.LW + ox0) * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + NT * i;
+        const int row = q / CPR, cc = q - row * CPR;
+        if (row < npx) *reinterpret_cast<v4f *>(base + (size_t)row * C + 8 * cc) = *reinterpret_cast<const v4f *>(buf + row * gpitch(C) + 8 * cc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward, pass 1: tiles[block][3][C] = (count, sum, M2 about the block mean) of h
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void c1m_stats_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, float *__restrict__ tiles, const C1Geom g)
+{
+    constexpr int NT = 64 * NW, C = 32 * NW;
+    __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5, c = 32 * wave + n;
+    bf16x8 whi, wlo;
+    load_w_operand(w, c, hb, whi, wlo);
+    const float bs = bias ? bias[c] : 0.f;
+    float pv = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+
+    int buf = 0;
+    float pr[PatchRegs<NT>::N];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load<NT>(pr, img, g, b, ly, ox0, tid);
+        patch_store<NT>(patch[0], pr, tid);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+        int b, ly, ox0;
+        tile_coords(g, tile, b, ly, ox0);
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load<NT>(pr, img, g, nb, nly, nox0, tid);
+        }
+        const int npx = min(TW, g.LW - ox0);
+        if (npx == TW) {          // full tile (the common case): every register is a real pixel
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
+                pv = cnt == 0.f ? h[0] : pv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = h[r] - pv;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, d, s2);
+                }
+                cnt += 16.f;
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (32 * mb >= npx) break;
+                const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = 32 * mb + acc_pixel(r, hb) < npx;
+                    pv = (cnt == 0.f && ok) ? h[r] : pv;
+                    const float d = ok ? h[r] - pv : 0.f;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, d, s2);
+                    cnt += ok ? 1.f : 0.f;
+                }
+            }
+        }
+        if (nxt < g.ntiles) patch_store<NT>(patch[buf ^ 1], pr, tid);
+        __syncthreads();
+    }
+    // the lane's (count, mean, M2), pooled with the other half-wave's lane of the same channel
+    const double n0 = cnt, inv = cnt > 0.f ? 1.0 / cnt : 0.0;
+    const double m0 = (double)pv + (double)s1 * inv;
+    double q0 = (double)s2 - (double)s1 * (double)s1 * inv;
+    q0 = q0 > 0.0 ? q0 : 0.0;
+    const double n1 = __shfl_xor(n0, 32, 64), m1 = __shfl_xor(m0, 32, 64), q1 = __shfl_xor(q0, 32, 64);
+    if (hb == 0) {
+        const double N = n0 + n1;
+        const double mu = N > 0.0 ? (n0 * m0 + n1 * m1) / N : 0.0;
+        const double Q = q0 + q1 + n0 * (m0 - mu) * (m0 - mu) + n1 * (m1 - mu) * (m1 - mu);
+        float *dst = tiles + (size_t)blockIdx.x * 3 * C;
+        dst[c] = (float)N;
+        dst[C + c] = (float)(N * mu);
+        dst[2 * C + c] = (float)Q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward, pass 2: y = max(fma(h, fs, off), 0) as bf16
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void c1m_apply_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, bf16_t *__restrict__ out, const C1Geom g)
+{
+    constexpr int NT = 64 * NW, C = 32 * NW;
+    __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
+    __shared__ __attribute__((aligned(16))) bf16_t ybuf[2][TW * gpitch(C)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5, c = 32 * wave + n;
+    bf16x8 whi, wlo;
+    load_w_operand(w, c, hb, whi, wlo);
+    const float bs = bias ? bias[c] : 0.f;
+    const float fs = invstd[c] * gamma[c];
+    const float off = __builtin_fmaf(-mean[c], fs, beta[c]);
+
+    int buf = 0;
+    float pr[PatchRegs<NT>::N];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load<NT>(pr, img, g, b, ly, ox0, tid);
+        patch_store<NT>(patch[0], pr, tid);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+        int b, ly, ox0;
+        tile_coords(g, tile, b, ly, ox0);
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load<NT>(pr, img, g, nb, nly, nox0, tid);
+        }
+        const int npx = min(TW, g.LW - ox0);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (32 * mb >= npx) break;
+            const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = fmaxf(__builtin_fmaf(h[r], fs, off), 0.f);
+                ybuf[buf][(32 * mb + acc_pixel(r, hb)) * gpitch(C) + c] = nsg_f2bf(y);    // rows >= npx: inside the buffer, never stored
+            }
+        }
+        if (nxt < g.ntiles) patch_store<NT>(patch[buf ^ 1], pr, tid);
+        __syncthreads();
+        gtile_store<NW>(out, ybuf[buf], g, b, ly, ox0, npx, tid);     // (the next tile writes the other buffer)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward, pass 1: partial[block][2][C] = (sum g, sum g*xhat)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void c1m_bwd_sums_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                                const float *__restrict__ bias, const bf16_t *__restrict__ dy,
+                                                                const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                float *__restrict__ partial, const C1Geom g)
+{
+    constexpr int NT = 64 * NW, C = 32 * NW;
+    __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
+    __shared__ __attribute__((aligned(16))) bf16_t gbuf[2][TW * gpitch(C)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5, c = 32 * wave + n;
+    bf16x8 whi, wlo;
+    load_w_operand(w, c, hb, whi, wlo);
+    const float bs = bias ? bias[c] : 0.f;
+    const float mu = mean[c], is = invstd[c];
+    const float fs = is * gamma[c];
+    const float off = __builtin_fmaf(-mu, fs, beta[c]);
+    float s1 = 0.f, s2 = 0.f;
+
+    int buf = 0;
+    float pr[PatchRegs<NT>::N];
+    v4f gr[4];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load<NT>(pr, img, g, b, ly, ox0, tid);
+        gtile_load<NW>(gr, dy, g, b, ly, ox0, min(TW, g.LW - ox0), tid);
+        patch_store<NT>(patch[0], pr, tid);
+        gtile_to_lds<NW>(gbuf[0], gr, tid);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+        int b, ly, ox0;
+        tile_coords(g, tile, b, ly, ox0);
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load<NT>(pr, img, g, nb, nly, nox0, tid);
+            gtile_load<NW>(gr, dy, g, nb, nly, nox0, min(TW, g.LW - nox0), tid);
+        }
+        const int npx = min(TW, g.LW - ox0);
+        auto body = [&](auto FULL) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (!decltype(FULL)::value && 32 * mb >= npx) break;
+                const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * mb + acc_pixel(r, hb);
+                    const float gv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
+                    bool pass = __builtin_fmaf(h[r], fs, off) > 0.f;
+                    if (!decltype(FULL)::value) pass = pass & (j < npx);
+                    const float ge = pass ? gv : 0.f;
+                    s1 += ge;
+                    s2 = __builtin_fmaf(ge, h[r] - mu, s2);
+                }
+            }
+        };
+        if (npx == TW) body(std::true_type{}); else body(std::false_type{});
+        if (nxt < g.ntiles) {
+            patch_store<NT>(patch[buf ^ 1], pr, tid);
+            gtile_to_lds<NW>(gbuf[buf ^ 1], gr, tid);
+        }
+        __syncthreads();
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hb == 0) {
+        float *dst = partial + (size_t)blockIdx.x * 2 * C;
+        dst[c] = s1;
+        dst[C + c] = s2 * is;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward, pass 2: dh on the spot, folded into partial[block][c][17] = 16 tap sums of dh*patch + the column sum of dh
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void c1m_bwd_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                                 const float *__restrict__ bias, const bf16_t *__restrict__ dy,
+                                                                 const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                                                                 float inv_m, float *__restrict__ partial, const C1Geom g)
+{
+    constexpr int NT = 64 * NW, C = 32 * NW;
+    __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
+    __shared__ __attribute__((aligned(16))) bf16_t gbuf[2][TW * gpitch(C)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5, c = 32 * wave + n;
+    bf16x8 whi, wlo;
+    load_w_operand(w, c, hb, whi, wlo);
+    const float bs = bias ? bias[c] : 0.f;
+    const float mu = mean[c], is = invstd[c];
+    const float fs = is * gamma[c];
+    const float off = __builtin_fmaf(-mu, fs, beta[c]);
+    const float sc = gamma[c] * is;
+    const float k1 = sc * is * (dgamma[c] * inv_m);
+    const float k0 = __builtin_fmaf(sc, dbeta[c] * inv_m, -(k1 * mu));
+    // this lane as a row of the patch^T operand: tap n (rows 16..31 of the operand are zero)
+    const unsigned tap_mask = n < 16 ? 0xffffffffu : 0u;
+    const int tap_off = ((n >> 2) & 3) * PP + (n & 3);
+    float cs = 0.f;
+    v16f dwacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+
+    int buf = 0;
+    float pr[PatchRegs<NT>::N];
+    v4f gr[4];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load<NT>(pr, img, g, b, ly, ox0, tid);
+        gtile_load<NW>(gr, dy, g, b, ly, ox0, min(TW, g.LW - ox0), tid);
+        patch_store<NT>(patch[0], pr, tid);
+        gtile_to_lds<NW>(gbuf[0], gr, tid);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+        int b, ly, ox0;
+        tile_coords(g, tile, b, ly, ox0);
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load<NT>(pr, img, g, nb, nly, nox0, tid);
+            gtile_load<NW>(gr, dy, g, nb, nly, nox0, min(TW, g.LW - nox0), tid);
+        }
+        const int npx = min(TW, g.LW - ox0);
+        auto body = [&](auto FULL) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (!decltype(FULL)::value && 32 * mb >= npx) break;
+                const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
+                float d[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * mb + acc_pixel(r, hb);
+                    const float gv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
+                    const float ge = __builtin_fmaf(h[r], fs, off) > 0.f ? gv : 0.f;
+                    const float dv = __builtin_fmaf(sc, ge, -__builtin_fmaf(k1, h[r], k0));
+                    d[r] = (decltype(FULL)::value || j < npx) ? dv : 0.f;
+                    cs += d[r];
+                }
+                // dw^T[tap][channel] += patch^T[tap][pixel] * d[pixel][channel]: two MFMAs of 16 pixels.  B: this lane's
+                // registers 8s .. 8s+7 (K index 8hb + i <-> pixel acc_pixel(8s + i, hb)); A: the same pixels' values of this
+                // lane's tap as bf16 (all lanes read -- lanes 16..31 a duplicate row -- and the padding rows are masked to zero).
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    v4u db, pa;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        db[i] = pack_bf16(d[8 * s + 2 * i], d[8 * s + 2 * i + 1]);
+                        const int j0 = 32 * mb + acc_pixel(8 * s + 2 * i, hb), j1 = 32 * mb + acc_pixel(8 * s + 2 * i + 1, hb);
+                        pa[i] = pack_bf16(patch[buf][tap_off + 2 * j0], patch[buf][tap_off + 2 * j1]) & tap_mask;
+                    }
+                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, db), dwacc, 0, 0, 0);
+                }
+            }
+        };
+        if (npx == TW) body(std::true_type{}); else body(std::false_type{});
+        if (nxt < g.ntiles) {
+            patch_store<NT>(patch[buf ^ 1], pr, tid);
+            gtile_to_lds<NW>(gbuf[buf ^ 1], gr, tid);
+        }
+        __syncthreads();
+    }
+    // rows of dwacc are taps: register r < 8 of a lane in half hb is tap acc_pixel(r, hb) < 16
+    float *dst = partial + ((size_t)blockIdx.x * C + c) * 17;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dst[acc_pixel(r, hb)] = dwacc[r];
+    cs += __shfl_xor(cs, 32, 64);
+    if (hb == 0) dst[16] = cs;
+}
+
+}  // namespace
+
+// ---- launchers (stencil_c1.hip's C ABI picks these for bf16 tensors with C = 32, 64, 96 or 128) ----
+bool nsg_c1m_supported(int C) { return C % 32 == 0 && C >= 32 && C <= 128; }
+
+#define NSG_C1M_DISPATCH(KERNEL, ...)                                                                                   \
+    switch (C / 32) {                                                                                                   \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(blocks), dim3(64), 0, s, __VA_ARGS__); break;                          \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(blocks), dim3(128), 0, s, __VA_ARGS__); break;                         \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(blocks), dim3(192), 0, s, __VA_ARGS__); break;                         \
+    default: hipLaunchKernelGGL((KERNEL<4>), dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;                        \
+    }
+
+int nsg_launch_c1m_stats(const float *img, const float *w, const float *bias, float *tiles, int blocks, int B, int LH, int LW, int HH, int WW,
+                         int C, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
+    NSG_C1M_DISPATCH(c1m_stats_kernel, img, w, bias, tiles, g)
+    return nsg_check_launch("c1m_stats_kernel");
+}
+
+int nsg_launch_c1m_apply(const float *img, const float *w, const float *bias, const float *mean, const float *invstd, const float *gamma,
+                         const float *beta, void *out, int blocks, int B, int LH, int LW, int HH, int WW, int C, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
+    NSG_C1M_DISPATCH(c1m_apply_kernel, img, w, bias, mean, invstd, gamma, beta, reinterpret_cast<bf16_t *>(out), g)
+    return nsg_check_launch("c1m_apply_kernel");
+}
+
+int nsg_launch_c1m_bwd_sums(const float *img, const float *w, const float *bias, const void *dy, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, float *partial, int blocks, int B, int LH, int LW, int HH, int WW, int C,
+                            hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
+    NSG_C1M_DISPATCH(c1m_bwd_sums_kernel, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, partial, g)
+    return nsg_check_launch("c1m_bwd_sums_kernel");
+}
+
+int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias, const void *dy, const float *mean, const float *invstd,
+                             const float *gamma, const float *beta, const float *dgamma, const float *dbeta, float inv_m, float *partial,
+                             int blocks, int B, int LH, int LW, int HH, int WW, int C, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
+    NSG_C1M_DISPATCH(c1m_bwd_wgrad_kernel, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, dgamma, dbeta, inv_m,
+                     partial, g)
+    return nsg_check_launch("c1m_bwd_wgrad_kernel");
+}

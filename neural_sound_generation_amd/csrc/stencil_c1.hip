@@ -12,25 +12,15 @@
 // stay in registers across a persistent loop over tiles.  w is the parameter's own layout: Conv2d (C,1,4,4) and
 // ConvTranspose2d (C,1,4,4) are both [c][16].
 #include "nsg_common.h"
+#include "c1_geom.h"
 
 namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int TW = 64;             // low-res pixels of one image row per tile
-constexpr int PP = 2 * TW + 4;     // patch row pitch (2*TW + 2 used)
-
-struct C1Geom {
-    int B, LH, LW, HH, WW, C;
-    int segs;                      // tiles per low-res row
-    int ntiles;
-    FastDiv div_segs, div_lh;
-};
-
 // The 4 image rows x (2*TW+2) columns a tile needs (out-of-image positions are zero: the conv padding), in two halves so
 // that the NEXT tile's global loads are in flight while the current tile is computed: patch_load -> registers,
 // patch_store -> LDS.  4*(2*TW+2) = 520 values = 3 per thread of 256 (the last partly).
-constexpr int PATCH_VALS = 4 * (2 * TW + 2);
 constexpr int PATCH_PER_THREAD = (PATCH_VALS + 255) / 256;
 __device__ __forceinline__ void patch_load(float (&r)[PATCH_PER_THREAD], const float *__restrict__ img, const C1Geom &g, int b, int ly, int ox0, int tid)
 {
@@ -56,14 +46,6 @@ __device__ __forceinline__ void patch_store(float *patch, const float (&r)[PATCH
             patch[rr * PP + cix] = r[q];
         }
     }
-}
-
-__device__ __forceinline__ void tile_coords(const C1Geom &g, int tile, int &b, int &ly, int &ox0)
-{
-    const int row = nsg_div(tile, g.div_segs);
-    ox0 = (tile - row * g.segs) * TW;
-    b = nsg_div(row, g.div_lh);
-    ly = row - b * g.LH;
 }
 
 // pixel j of the tile: its 16 taps as 8 pairs (kw pairs), tap index t = 4*kh + kw
@@ -612,17 +594,6 @@ __global__ __launch_bounds__(256) void c1_bn_bwd_wgrad_kernel(const float *__res
     }
 }
 
-C1Geom make_geom(int B, int LH, int LW, int HH, int WW, int C)
-{
-    C1Geom g;
-    g.B = B; g.LH = LH; g.LW = LW; g.HH = HH; g.WW = WW; g.C = C;
-    g.segs = (LW + TW - 1) / TW;
-    g.ntiles = B * LH * g.segs;
-    g.div_segs = nsg_fastdiv((uint32_t)g.segs);
-    g.div_lh = nsg_fastdiv((uint32_t)LH);
-    return g;
-}
-
 constexpr int WGRAD_BLOCKS = 1024;
 
 }  // namespace
@@ -663,6 +634,19 @@ int nsg_launch_c1_stencil_wgrad(const float *img, const void *t, int t_dtype, in
 }
 
 // ---- the fused Conv2d(1, C, 4, 2, 1) + BatchNorm2d + ReLU layer (C ABI: include/nsg.h) ----
+// c1_mfma.hip: the same four passes with the convolution on the matrix cores, for bf16 tensors
+bool nsg_c1m_supported(int C);
+int nsg_launch_c1m_stats(const float *img, const float *w, const float *bias, float *tiles, int blocks, int B, int LH, int LW, int HH, int WW,
+                         int C, hipStream_t s);
+int nsg_launch_c1m_apply(const float *img, const float *w, const float *bias, const float *mean, const float *invstd, const float *gamma,
+                         const float *beta, void *out, int blocks, int B, int LH, int LW, int HH, int WW, int C, hipStream_t s);
+int nsg_launch_c1m_bwd_sums(const float *img, const float *w, const float *bias, const void *dy, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, float *partial, int blocks, int B, int LH, int LW, int HH, int WW, int C,
+                            hipStream_t s);
+int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias, const void *dy, const float *mean, const float *invstd,
+                             const float *gamma, const float *beta, const float *dgamma, const float *dbeta, float inv_m, float *partial,
+                             int blocks, int B, int LH, int LW, int HH, int WW, int C, hipStream_t s);
+
 namespace {
 constexpr int FUSED_BLOCKS = 1024;      // = bn.hip's MAX_SLABS (bn_bwd_final_kernel) and WGRAD_BLOCKS
 size_t fused_tiles_bytes(int C) { return nsg_align_up((size_t)2 * FUSED_BLOCKS * 3 * C * sizeof(float), 256); }
@@ -698,17 +682,25 @@ int nsg_c1conv_bn_relu_forward(const float *img, const float *w, const float *bi
     NSG_REQUIRE(nsg_aligned16(w) && nsg_aligned16(y), NSG_E_INVALID, "nsg_c1conv_bn_relu_forward: w and y must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const C1Geom g = make_geom(B, H / 2, W / 2, H, W, C);
+    // bf16 output: the passes with the convolution on the matrix cores (c1_mfma.hip); the statistics then come from the
+    // same instruction sequence as the values they normalise
+    const bool mfma = y_dtype == NSG_BF16 && nsg_c1m_supported(C);
     if (training) {
         NSG_REQUIRE(workspace && workspace_bytes >= nsg_c1conv_bn_workspace_bytes(C), NSG_E_WORKSPACE, "nsg_c1conv_bn_relu_forward: workspace too small");
         const int blocks = g.ntiles < 2 * FUSED_BLOCKS ? g.ntiles : 2 * FUSED_BLOCKS;
         float *tiles = reinterpret_cast<float *>(workspace);
-        hipLaunchKernelGGL(c1_bn_stats_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, tiles, g);
-        rc = nsg_check_launch("c1_bn_stats_kernel");
+        if (mfma) {
+            rc = nsg_launch_c1m_stats(img, w, bias, tiles, blocks, B, g.LH, g.LW, H, W, C, s);
+        } else {
+            hipLaunchKernelGGL(c1_bn_stats_kernel, dim3(blocks), dim3(256), 0, s, img, w, bias, tiles, g);
+            rc = nsg_check_launch("c1_bn_stats_kernel");
+        }
         if (rc) return rc;
         rc = nsg_bn_stats_from_tiles(tiles, blocks, (int64_t)B * g.LH * g.LW, C, eps, momentum, mean, invstd, running_mean, running_var, s);
         if (rc) return rc;
     }
     const int blocks = g.ntiles < 2048 ? g.ntiles : 2048;
+    if (mfma) return nsg_launch_c1m_apply(img, w, bias, mean, invstd, gamma, beta, y, blocks, B, g.LH, g.LW, H, W, C, s);
     if (y_dtype == NSG_BF16)
         hipLaunchKernelGGL((c1_bn_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, img, w, bias, mean, invstd, gamma, beta, reinterpret_cast<bf16_t *>(y), g);
     else
@@ -733,6 +725,16 @@ int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const float *b
     float *sums = reinterpret_cast<float *>(workspace);
     float *partial17 = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + fused_sums_bytes(C));
     const float inv_m = 1.f / (float)((int64_t)B * g.LH * g.LW);
+    if (dy_dtype == NSG_BF16 && nsg_c1m_supported(C)) {     // the forward's choice for bf16 tensors: the same h, the same ReLU decisions
+        rc = nsg_launch_c1m_bwd_sums(img, w, bias, dy, mean, invstd, gamma, beta, sums, blocks, B, g.LH, g.LW, H, W, C, s);
+        if (rc) return rc;
+        rc = nsg_launch_bn_bwd_final(sums, blocks, C, dgamma, dbeta, s);
+        if (rc) return rc;
+        rc = nsg_launch_c1m_bwd_wgrad(img, w, bias, dy, mean, invstd, gamma, beta, dgamma, dbeta, inv_m, partial17, blocks, B, g.LH, g.LW, H, W, C, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(c1_stencil_wgrad_final_kernel, dim3((C * 17 + 31) / 32), dim3(256), 0, s, partial17, blocks, C, dw, dbias);
+        return nsg_check_launch("c1_stencil_wgrad_final_kernel");
+    }
     if (dy_dtype == NSG_BF16)
         hipLaunchKernelGGL((c1_bn_bwd_sums_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, sums, g);
     else

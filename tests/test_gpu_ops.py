@@ -464,7 +464,8 @@ def test_batchnorm_train_forward_backward(B, C, H, W, relu, res):
     _close(dbg.cpu(), gb, tol=3e-5, what="bn dbeta")
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 80, 64, 128), (2, 20, 260, 48), (1, 6, 130, 256), (2, 4, 4, 4)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 80, 64, 128), (2, 20, 260, 48), (1, 6, 130, 256), (2, 4, 4, 4),
+                                     (2, 20, 260, 96), (1, 6, 130, 32), (2, 8, 12, 64), (2, 10, 300, 128)])
 @pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16"])
 def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
     """encoder.0-2 (Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU, src/models.py:165-167) as one operator whose conv output is
