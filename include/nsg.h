@@ -268,6 +268,32 @@ NSG_API int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const 
                                         int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The single-channel OUTPUT layer with the BatchNorm in front of it, as one operator     src/models.py:180-183
+ *   decoder.4 BatchNorm2d(C) -> decoder.5 ReLU(True) -> decoder.6 ConvTranspose2d(C, 1, 4, 2, 1) [-> decoder.7 Tanh]
+ * u [B][H][W][C] is the BatchNorm INPUT (the transposed conv in front wrote it; its batch statistics come from
+ * nsg_bn_stats).  Neither the activated tensor a = relu(bn(u)) nor the data gradient of the transposed conv is ever
+ * stored: the forward applies BatchNorm + ReLU on the operand's way into the MFMA, the backward rebuilds the
+ * data gradient from the gradient image (16 taps per element, on the matrix cores) inside the BatchNorm-backward
+ * passes and the weight gradient from a rebuilt on the spot -- 4 tensor reads + 1 write against 8 reads + 3 writes
+ * of nsg_bn_apply + nsg_conv_forward + nsg_conv_wgrad + nsg_conv_dgrad + nsg_bn_backward.
+ * Available for bf16 tensors with C = 32, 64, 96, 128 (nsg_bn_relu_c1convt_supported); other shapes use the
+ * separate operators.  w: the parameter's own layout (C,1,4,4) = [C][16] fp32; y / dy: [B][2H][2W] fp32.
+ * ------------------------------------------------------------------------------------------- */
+NSG_API int32_t nsg_bn_relu_c1convt_supported(int32_t dtype, int32_t C);
+NSG_API size_t nsg_bn_relu_c1convt_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C);
+/* y = [tanh](bias + convT(relu((u - mean) * invstd * gamma + beta)));  flags: 0 or NSG_TANH_OUT */
+NSG_API int nsg_bn_relu_c1convt_forward(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma,
+                                        const float *beta, const float *w, const float *bias, float *y, int32_t flags, int32_t B,
+                                        int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes, void *stream);
+/* dy: gradient w.r.t. the transposed conv's output (BEFORE the tanh: nsg_tanh_backward).  Outputs: du (dtype, the
+ * gradient w.r.t. u), du_colsum [C] or NULL (column sums of du = the bias gradient of the conv that wrote u, as
+ * nsg_bn_backward's dx_colsum), dw [C][16], dbias [1] or NULL, dgamma [C], dbeta [C], all overwritten. */
+NSG_API int nsg_bn_relu_c1convt_backward(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma,
+                                         const float *beta, const float *w, const float *dy, void *du, float *du_colsum, float *dw,
+                                         float *dbias, float *dgamma, float *dbeta, int32_t B, int32_t H, int32_t W, int32_t C,
+                                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Element-wise, losses, optimiser                         src/train.py:118-136
  * ------------------------------------------------------------------------------------------- */
 

@@ -67,6 +67,11 @@ _SIGS = {
                                           c_int32, _P, c_size_t, _P]),
     "nsg_c1conv_bn_relu_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
                                            c_size_t, _P]),
+    "nsg_bn_relu_c1convt_supported": (c_int32, [c_int32, c_int32]),
+    "nsg_bn_relu_c1convt_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "nsg_bn_relu_c1convt_forward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_relu_c1convt_backward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
+                                            c_size_t, _P]),
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, c_int32, _P]),
     "nsg_convert": (None, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),

@@ -297,8 +297,13 @@ __global__ __launch_bounds__(64 * NW) void c1m_apply_kernel(const float *__restr
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward, pass 1: partial[block][2][C] = (sum g, sum g*xhat)
+// SWAP = false: the input layer (BatchNorm input = the recomputed conv value h, incoming gradient = the tensor dy).
+// SWAP = true:  the OUTPUT layer BatchNorm -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) (src/models.py:180-182): the roles
+//               are exchanged -- the tensor is the BatchNorm input u, and the gradient that reaches the ReLU is the data
+//               gradient of the transposed conv, da[pix][c] = sum_t patch(dpre)[t] * w[c][t]: the same MFMA block, built
+//               from the gradient image dpre and never stored.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool SWAP>
 __global__ __launch_bounds__(64 * NW) void c1m_bwd_sums_kernel(const float *__restrict__ img, const float *__restrict__ w,
                                                                 const float *__restrict__ bias, const bf16_t *__restrict__ dy,
                                                                 const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -349,12 +354,13 @@ __global__ __launch_bounds__(64 * NW) void c1m_bwd_sums_kernel(const float *__re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = 32 * mb + acc_pixel(r, hb);
-                    const float gv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
-                    bool pass = __builtin_fmaf(h[r], fs, off) > 0.f;
+                    const float tv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
+                    const float x = SWAP ? tv : h[r], gv = SWAP ? h[r] : tv;     // BatchNorm input, incoming gradient
+                    bool pass = __builtin_fmaf(x, fs, off) > 0.f;
                     if (!decltype(FULL)::value) pass = pass & (j < npx);
                     const float ge = pass ? gv : 0.f;
                     s1 += ge;
-                    s2 = __builtin_fmaf(ge, h[r] - mu, s2);
+                    s2 = __builtin_fmaf(ge, x - mu, s2);
                 }
             }
         };
@@ -377,13 +383,17 @@ __global__ __launch_bounds__(64 * NW) void c1m_bwd_sums_kernel(const float *__re
 // ---------------------------------------------------------------------------------------------------------------
 // backward, pass 2: dh on the spot, folded into partial[block][c][17] = 16 tap sums of dh*patch + the column sum of dh
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW>
+// SWAP = true (the output layer, see c1m_bwd_sums_kernel): the tensor is u; du = BatchNorm backward of the recomputed da is
+// written back over the tile in LDS and stored (dx_out), and the weight gradient of the transposed conv accumulates
+// dw^T[tap][c] += patch(dpre)^T[tap][pixel] * a[pixel][c] with a = max(fma(u, fs, off), 0) rebuilt on the spot.
+template <int NW, bool SWAP>
 __global__ __launch_bounds__(64 * NW) void c1m_bwd_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ w,
                                                                  const float *__restrict__ bias, const bf16_t *__restrict__ dy,
                                                                  const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta,
-                                                                 float inv_m, float *__restrict__ partial, const C1Geom g)
+                                                                 float inv_m, float *__restrict__ partial, bf16_t *__restrict__ dx_out,
+                                                                 const C1Geom g)
 {
     constexpr int NT = 64 * NW, C = 32 * NW;
     __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
@@ -439,11 +449,19 @@ __global__ __launch_bounds__(64 * NW) void c1m_bwd_wgrad_kernel(const float *__r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = 32 * mb + acc_pixel(r, hb);
-                    const float gv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
-                    const float ge = __builtin_fmaf(h[r], fs, off) > 0.f ? gv : 0.f;
-                    const float dv = __builtin_fmaf(sc, ge, -__builtin_fmaf(k1, h[r], k0));
-                    d[r] = (decltype(FULL)::value || j < npx) ? dv : 0.f;
-                    cs += d[r];
+                    const float tv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
+                    const float x = SWAP ? tv : h[r], gv = SWAP ? h[r] : tv;
+                    const float t = __builtin_fmaf(x, fs, off);
+                    const float ge = t > 0.f ? gv : 0.f;
+                    const float dv = __builtin_fmaf(sc, ge, -__builtin_fmaf(k1, x, k0));
+                    if (SWAP) {
+                        gbuf[buf][j * gpitch(C) + c] = nsg_f2bf(dv);      // over the element this lane just read; rows >= npx never leave LDS
+                        d[r] = (decltype(FULL)::value || j < npx) ? fmaxf(t, 0.f) : 0.f;
+                        cs += (decltype(FULL)::value || j < npx) ? dv : 0.f;     // column sum of du: the bias gradient of the conv in front
+                    } else {
+                        d[r] = (decltype(FULL)::value || j < npx) ? dv : 0.f;
+                        cs += d[r];
+                    }
                 }
                 // dw^T[tap][channel] += patch^T[tap][pixel] * d[pixel][channel]: two MFMAs of 16 pixels.  B: this lane's
                 // registers 8s .. 8s+7 (K index 8hb + i <-> pixel acc_pixel(8s + i, hb)); A: the same pixels' values of this
@@ -462,6 +480,10 @@ __global__ __launch_bounds__(64 * NW) void c1m_bwd_wgrad_kernel(const float *__r
             }
         };
         if (npx == TW) body(std::true_type{}); else body(std::false_type{});
+        if (SWAP) {
+            __syncthreads();                                              // the du tile is complete in gbuf[buf]
+            gtile_store<NW>(dx_out, gbuf[buf], g, b, ly, ox0, npx, tid);
+        }
         if (nxt < g.ntiles) {
             patch_store<NT>(patch[buf ^ 1], pr, tid);
             gtile_to_lds<NW>(gbuf[buf ^ 1], gr, tid);
@@ -476,6 +498,95 @@ __global__ __launch_bounds__(64 * NW) void c1m_bwd_wgrad_kernel(const float *__r
     if (hb == 0) dst[16] = cs;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The output layer's forward: dots[m][t] = sum_c max(fma(u[m][c], fs[c], off[c]), 0) * w[c][t], m over all B*LH*LW pixels
+// (the BatchNorm apply + ReLU happen on the operand's way into the MFMA: the activated tensor is never stored); the
+// 16 tap products of a pixel are then scattered onto the image by col2im_c1_kernel (conv_api.hip) with bias and tanh.
+// bf16 operands (a rounded to bf16 exactly as the backward rebuilds it, w rounded to bf16), fp32 accumulate.
+// Block = 4 waves = 128 rows; MFMA out[tap][pixel] = w^T[tap][K = 16 channels] * a^T[K][pixel]: a lane is a pixel and
+// reads its 8 consecutive channels of the k-step as one 16-byte LDS read of the row-major tile.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>     // C = 32 NW
+__global__ __launch_bounds__(256) void bnrelu_dots_kernel(const bf16_t *__restrict__ u, const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ w,
+                                                          float *__restrict__ dots, int64_t M)
+{
+    constexpr int C = 32 * NW, KS = C / 16, ROWS = 128, CPR = C / 8, PIECES = ROWS * CPR / 256;   // 16-byte pieces per thread
+    __shared__ __attribute__((aligned(16))) bf16_t tile[ROWS * gpitch(C)];
+    __shared__ __attribute__((aligned(16))) float cfs[C], coff[C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5;
+    for (int c = tid; c < C; c += 256) {
+        const float fs = invstd[c] * gamma[c];
+        cfs[c] = fs;
+        coff[c] = __builtin_fmaf(-mean[c], fs, beta[c]);
+    }
+    // A operand per k-step: lane (tap n, hb) holds w[16 ks + 8 hb + i][n], i = 0..7, as bf16 (rows 16..31 zero)
+    v4u wa[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c0 = 16 * ks + 8 * hb + 2 * i;
+            wa[ks][i] = n < 16 ? pack_bf16(w[(size_t)c0 * 16 + n], w[(size_t)(c0 + 1) * 16 + n]) : 0u;
+        }
+    const int64_t ntiles = (M + ROWS - 1) / ROWS;
+    v4f pr[PIECES];
+    auto prefetch = [&](int64_t t) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int q = tid + 256 * i;
+            const int row = q / CPR, cc = q - row * CPR;
+            const int64_t m = t * ROWS + row;
+            pr[i] = *reinterpret_cast<const v4f *>(u + (size_t)(m < M ? m : M - 1) * C + 8 * cc);   // clamped
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int q = tid + 256 * i;
+            const int row = q / CPR, cc = q - row * CPR;
+            *reinterpret_cast<v4f *>(tile + row * gpitch(C) + 8 * cc) = pr[i];
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) { prefetch(blockIdx.x); stage(); }
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t nxt = t + gridDim.x;
+        if (nxt < ntiles) prefetch(nxt);
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bf16_t *rowp = tile + (32 * wave + n) * gpitch(C) + 8 * hb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4f raw = *reinterpret_cast<const v4f *>(rowp + 16 * ks);
+            const v4f f0 = *reinterpret_cast<const v4f *>(cfs + 16 * ks + 8 * hb), f1 = *reinterpret_cast<const v4f *>(cfs + 16 * ks + 8 * hb + 4);
+            const v4f o0 = *reinterpret_cast<const v4f *>(coff + 16 * ks + 8 * hb), o1 = *reinterpret_cast<const v4f *>(coff + 16 * ks + 8 * hb + 4);
+            const float fs8[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            const float of8[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            float uv[8];
+            Elem<bf16_t>::unpack16(raw, uv);
+            v4u a;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = pack_bf16(fmaxf(__builtin_fmaf(uv[2 * i], fs8[2 * i], of8[2 * i]), 0.f),
+                                 fmaxf(__builtin_fmaf(uv[2 * i + 1], fs8[2 * i + 1], of8[2 * i + 1]), 0.f));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[ks]), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+        }
+        // lane (pixel n, hb): registers r < 8 are taps (r & 3) + 8 (r >> 2) + 4 hb: two runs of 4 consecutive taps
+        const int64_t m = t * ROWS + 32 * wave + n;
+        if (m < M) {
+            *reinterpret_cast<v4f *>(dots + (size_t)m * 16 + 4 * hb) = v4f{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<v4f *>(dots + (size_t)m * 16 + 8 + 4 * hb) = v4f{acc[4], acc[5], acc[6], acc[7]};
+        }
+        __syncthreads();                 // everyone is done reading the tile
+        if (nxt < ntiles) stage();
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // ---- launchers (stencil_c1.hip's C ABI picks these for bf16 tensors with C = 32, 64, 96 or 128) ----
@@ -487,6 +598,14 @@ bool nsg_c1m_supported(int C) { return C % 32 == 0 && C >= 32 && C <= 128; }
     case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(blocks), dim3(128), 0, s, __VA_ARGS__); break;                         \
     case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(blocks), dim3(192), 0, s, __VA_ARGS__); break;                         \
     default: hipLaunchKernelGGL((KERNEL<4>), dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;                        \
+    }
+
+#define NSG_C1M_DISPATCH2(KERNEL, FLAG, ...)                                                                            \
+    switch (C / 32) {                                                                                                   \
+    case 1: hipLaunchKernelGGL((KERNEL<1, FLAG>), dim3(blocks), dim3(64), 0, s, __VA_ARGS__); break;                    \
+    case 2: hipLaunchKernelGGL((KERNEL<2, FLAG>), dim3(blocks), dim3(128), 0, s, __VA_ARGS__); break;                   \
+    case 3: hipLaunchKernelGGL((KERNEL<3, FLAG>), dim3(blocks), dim3(192), 0, s, __VA_ARGS__); break;                   \
+    default: hipLaunchKernelGGL((KERNEL<4, FLAG>), dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;                  \
     }
 
 int nsg_launch_c1m_stats(const float *img, const float *w, const float *bias, float *tiles, int blocks, int B, int LH, int LW, int HH, int WW,
@@ -510,7 +629,7 @@ int nsg_launch_c1m_bwd_sums(const float *img, const float *w, const float *bias,
                             hipStream_t s)
 {
     const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
-    NSG_C1M_DISPATCH(c1m_bwd_sums_kernel, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, partial, g)
+    NSG_C1M_DISPATCH2(c1m_bwd_sums_kernel, false, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, partial, g)
     return nsg_check_launch("c1m_bwd_sums_kernel");
 }
 
@@ -519,7 +638,44 @@ int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias
                              int blocks, int B, int LH, int LW, int HH, int WW, int C, hipStream_t s)
 {
     const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
-    NSG_C1M_DISPATCH(c1m_bwd_wgrad_kernel, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, dgamma, dbeta, inv_m,
-                     partial, g)
+    NSG_C1M_DISPATCH2(c1m_bwd_wgrad_kernel, false, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, dgamma, dbeta,
+                      inv_m, partial, (bf16_t *)nullptr, g)
     return nsg_check_launch("c1m_bwd_wgrad_kernel");
+}
+
+// ---- the output layer BatchNorm -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) (conv_api.hip: nsg_bn_relu_c1convt_*) ----
+int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
+                           float *dots, int64_t M, int C, hipStream_t s)
+{
+    int64_t blocks = (M + 127) / 128;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) return NSG_OK;
+    const bf16_t *ub = reinterpret_cast<const bf16_t *>(u);
+    switch (C / 32) {
+    case 1: hipLaunchKernelGGL((bnrelu_dots_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
+    case 2: hipLaunchKernelGGL((bnrelu_dots_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
+    case 3: hipLaunchKernelGGL((bnrelu_dots_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
+    default: hipLaunchKernelGGL((bnrelu_dots_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
+    }
+    return nsg_check_launch("bnrelu_dots_kernel");
+}
+
+// dimg: the gradient image [B][2 LH][2 LW] fp32 (w.r.t. the transposed conv's output); u, du: [B][LH][LW][C] bf16
+int nsg_launch_c1m_out_bwd_sums(const float *dimg, const float *w, const void *u, const float *mean, const float *invstd, const float *gamma,
+                                const float *beta, float *partial, int blocks, int B, int LH, int LW, int C, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, 2 * LH, 2 * LW, C);
+    NSG_C1M_DISPATCH2(c1m_bwd_sums_kernel, true, dimg, w, (const float *)nullptr, reinterpret_cast<const bf16_t *>(u), mean, invstd, gamma, beta,
+                      partial, g)
+    return nsg_check_launch("c1m_bwd_sums_kernel<out>");
+}
+
+int nsg_launch_c1m_out_bwd_apply(const float *dimg, const float *w, const void *u, const float *mean, const float *invstd, const float *gamma,
+                                 const float *beta, const float *dgamma, const float *dbeta, float inv_m, float *partial17, void *du, int blocks,
+                                 int B, int LH, int LW, int C, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, 2 * LH, 2 * LW, C);
+    NSG_C1M_DISPATCH2(c1m_bwd_wgrad_kernel, true, dimg, w, (const float *)nullptr, reinterpret_cast<const bf16_t *>(u), mean, invstd, gamma, beta,
+                      dgamma, dbeta, inv_m, partial17, reinterpret_cast<bf16_t *>(du), g)
+    return nsg_check_launch("c1m_bwd_wgrad_kernel<out>");
 }

@@ -12,6 +12,16 @@ bool nsg_c1_stencil_supported(int C);
 size_t nsg_c1_stencil_wgrad_workspace_bytes(int C);
 int nsg_launch_c1_stencil_fwd(const float *img, const float *w, const float *bias, void *out, int out_dtype, int B, int LH, int LW,
                               int HH, int WW, int C, hipStream_t s);
+// c1_mfma.hip / stencil_c1.hip: pieces of the fused output layer (nsg_bn_relu_c1convt_*)
+bool nsg_c1m_supported(int C);
+int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
+                           float *dots, int64_t M, int C, hipStream_t s);
+int nsg_launch_c1m_out_bwd_sums(const float *dimg, const float *w, const void *u, const float *mean, const float *invstd, const float *gamma,
+                                const float *beta, float *partial, int blocks, int B, int LH, int LW, int C, hipStream_t s);
+int nsg_launch_c1m_out_bwd_apply(const float *dimg, const float *w, const void *u, const float *mean, const float *invstd, const float *gamma,
+                                 const float *beta, const float *dgamma, const float *dbeta, float inv_m, float *partial17, void *du, int blocks,
+                                 int B, int LH, int LW, int C, hipStream_t s);
+int nsg_launch_c1_stencil_wgrad_final(const float *partial17, int blocks, int C, float *dw, float *colsum, hipStream_t s);
 int nsg_launch_c1_stencil_wgrad(const float *img, const void *t, int t_dtype, int relu_t, float *dw, float *colsum, int B, int LH,
                                 int LW, int HH, int WW, int C, void *ws, size_t ws_bytes, hipStream_t s);
 
@@ -549,6 +559,75 @@ int nsg_conv_wgrad(const nsg_conv_desc *d, const void *x, const void *dy, float 
     if (rc) return rc;
     ws += wg_bytes;
     if (dbias) return colsum(dy, d->dtype, (int64_t)d->B * d->OH * d->OW, d->C_out, dbias, ws, s);
+    return NSG_OK;
+}
+
+/* ---- decoder.4 .. decoder.6 as one operator: BatchNorm2d -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) [-> Tanh] ---- */
+int32_t nsg_bn_relu_c1convt_supported(int32_t dtype, int32_t C) { return dtype == NSG_BF16 && nsg_c1m_supported(C) ? 1 : 0; }
+
+size_t nsg_bn_relu_c1convt_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const size_t fwd = nsg_align_up((size_t)B * H * W * 16 * sizeof(float), 256);
+    const size_t bwd = nsg_align_up((size_t)1024 * 2 * C * sizeof(float), 256) + nsg_c1_stencil_wgrad_workspace_bytes(C) +
+                       colsum_ws_bytes((int64_t)B * 4 * H * W, 1);
+    return fwd > bwd ? fwd : bwd;
+}
+
+int nsg_bn_relu_c1convt_forward(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                const float *w, const float *bias, float *y, int32_t flags, int32_t B, int32_t H, int32_t W, int32_t C,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(u && mean && invstd && gamma && beta && w && y, NSG_E_INVALID, "nsg_bn_relu_c1convt_forward: null pointer");
+    NSG_REQUIRE(B > 0 && H > 0 && W > 0, NSG_E_INVALID, "nsg_bn_relu_c1convt_forward: bad extent");
+    NSG_REQUIRE(nsg_bn_relu_c1convt_supported(dtype, C), NSG_E_UNSUPPORTED,
+                "nsg_bn_relu_c1convt_forward: needs bf16 tensors and C = 32, 64, 96 or 128 (use the separate operators otherwise)");
+    NSG_REQUIRE(!(flags & ~NSG_TANH_OUT), NSG_E_UNSUPPORTED, "nsg_bn_relu_c1convt_forward: only NSG_TANH_OUT");
+    NSG_REQUIRE(nsg_aligned16(u) && nsg_aligned16(w), NSG_E_INVALID, "nsg_bn_relu_c1convt_forward: u and w must be 16-byte aligned");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_bn_relu_c1convt_workspace_bytes(B, H, W, C), NSG_E_WORKSPACE,
+                "nsg_bn_relu_c1convt_forward: workspace too small");
+    NSG_REQUIRE((int64_t)B * H * W * C <= 0x7fffffffLL * 4, NSG_E_UNSUPPORTED, "nsg_bn_relu_c1convt_forward: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    float *dots = reinterpret_cast<float *>(workspace);
+    int rc = nsg_launch_bnrelu_dots(u, mean, invstd, gamma, beta, w, dots, (int64_t)B * H * W, C, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)B * 4 * H * W)), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H, 2 * W,
+                       (flags & NSG_TANH_OUT) ? 1 : 0);
+    return nsg_check_launch("col2im_c1_kernel");
+}
+
+int nsg_bn_relu_c1convt_backward(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                 const float *w, const float *dy, void *du, float *du_colsum, float *dw, float *dbias, float *dgamma,
+                                 float *dbeta, int32_t B, int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes,
+                                 void *stream)
+{
+    NSG_REQUIRE(u && mean && invstd && gamma && beta && w && dy && du && dw && dgamma && dbeta, NSG_E_INVALID,
+                "nsg_bn_relu_c1convt_backward: null pointer");
+    NSG_REQUIRE(B > 0 && H > 0 && W > 0, NSG_E_INVALID, "nsg_bn_relu_c1convt_backward: bad extent");
+    NSG_REQUIRE(nsg_bn_relu_c1convt_supported(dtype, C), NSG_E_UNSUPPORTED,
+                "nsg_bn_relu_c1convt_backward: needs bf16 tensors and C = 32, 64, 96 or 128 (use the separate operators otherwise)");
+    NSG_REQUIRE(nsg_aligned16(u) && nsg_aligned16(du) && nsg_aligned16(w), NSG_E_INVALID, "nsg_bn_relu_c1convt_backward: u, du and w must be 16-byte aligned");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_bn_relu_c1convt_workspace_bytes(B, H, W, C), NSG_E_WORKSPACE,
+                "nsg_bn_relu_c1convt_backward: workspace too small");
+    NSG_REQUIRE((int64_t)B * H * W * C <= 0x7fffffffLL * 4, NSG_E_UNSUPPORTED, "nsg_bn_relu_c1convt_backward: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *sums = reinterpret_cast<float *>(ws);
+    ws += nsg_align_up((size_t)1024 * 2 * C * sizeof(float), 256);
+    float *partial17 = reinterpret_cast<float *>(ws);
+    ws += nsg_c1_stencil_wgrad_workspace_bytes(C);
+    const int64_t ntiles = (int64_t)B * H * ((W + 63) / 64);
+    const int blocks = (int)(ntiles < 1024 ? ntiles : 1024);
+    const float inv_m = 1.f / (float)((int64_t)B * H * W);
+    int rc = nsg_launch_c1m_out_bwd_sums(dy, w, u, mean, invstd, gamma, beta, sums, blocks, B, H, W, C, s);
+    if (rc) return rc;
+    rc = nsg_launch_bn_bwd_final(sums, blocks, C, dgamma, dbeta, s);
+    if (rc) return rc;
+    rc = nsg_launch_c1m_out_bwd_apply(dy, w, u, mean, invstd, gamma, beta, dgamma, dbeta, inv_m, partial17, du, blocks, B, H, W, C, s);
+    if (rc) return rc;
+    rc = nsg_launch_c1_stencil_wgrad_final(partial17, blocks, C, dw, du_colsum, s);
+    if (rc) return rc;
+    if (dbias) return colsum(dy, NSG_F32, (int64_t)B * 4 * H * W, 1, dbias, ws, s);
     return NSG_OK;
 }
 

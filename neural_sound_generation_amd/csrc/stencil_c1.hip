@@ -633,6 +633,12 @@ int nsg_launch_c1_stencil_wgrad(const float *img, const void *t, int t_dtype, in
     return nsg_check_launch("c1_stencil_wgrad_final_kernel");
 }
 
+int nsg_launch_c1_stencil_wgrad_final(const float *partial17, int blocks, int C, float *dw, float *colsum, hipStream_t s)
+{
+    hipLaunchKernelGGL(c1_stencil_wgrad_final_kernel, dim3((C * 17 + 31) / 32), dim3(256), 0, s, partial17, blocks, C, dw, colsum);
+    return nsg_check_launch("c1_stencil_wgrad_final_kernel");
+}
+
 // ---- the fused Conv2d(1, C, 4, 2, 1) + BatchNorm2d + ReLU layer (C ABI: include/nsg.h) ----
 // c1_mfma.hip: the same four passes with the convolution on the matrix cores, for bf16 tensors
 bool nsg_c1m_supported(int C);

@@ -72,6 +72,10 @@ FUSED_BN_STATS = _os.environ.get("NSG_FUSED_BN_STATS", "0") == "1"
 # (ops.c1conv_bn_relu_*): measured on MI355X, bf16, B=128: see DESIGN.md section 3.  NSG_FUSED_C1_LAYER=0 restores
 # the four separate operators (same values: the fused passes recompute the conv output bit for bit).
 FUSED_C1_LAYER = _os.environ.get("NSG_FUSED_C1_LAYER", "1") == "1"
+# decoder.4-7 (BatchNorm -> ReLU -> ConvTranspose2d(D, 1, 4, 2, 1) -> Tanh) as one operator that stores neither the activated
+# tensor nor the transposed conv's data gradient (ops.bn_relu_c1convt_*; bf16 tensors, D = 32..128).  NSG_FUSED_OUT_LAYER=0
+# restores the separate operators.
+FUSED_OUT_LAYER = _os.environ.get("NSG_FUSED_OUT_LAYER", "1") == "1"
 
 
 # num_batches_tracked += 1 per BatchNorm is ten tiny launches a step; a fused step collects the counters here
@@ -238,10 +242,14 @@ def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, p
     dT = ops.conv_desc(B, H, W, D, D, 4, 2, 1, transposed=True, dtype=dtype)
     wfT, wdT = pk["convt3"] if packs is not None else ops.pack_weights(dT, P.convt3.weight)
     u, m, i = _conv_bn(dT, r1, wfT, P.convt3, P.bn4, training)
-    a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
     d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True, dtype=dtype)
-    wf6, wd6 = pk["convt6"] if packs is not None else ops.pack_weights(d6, P.convt6.weight)
-    xt = ops.conv_forward(d6, a, wf6, P.convt6.bias, flags=NSG_TANH_OUT)  # decoder.7 Tanh fused into the epilogue
+    if FUSED_OUT_LAYER and ops.bn_relu_c1convt_supported(u.dtype, D):
+        a, wd6 = None, None                          # relu(bn(u)) is never materialised; the backward rebuilds it from u
+        xt = ops.bn_relu_c1convt_forward(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias, tanh=True)
+    else:
+        a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
+        wf6, wd6 = pk["convt6"] if packs is not None else ops.pack_weights(d6, P.convt6.weight)
+        xt = ops.conv_forward(d6, a, wf6, P.convt6.bias, flags=NSG_TANH_OUT)  # decoder.7 Tanh fused into the epilogue
     saved = (r1, u, a, m, i, xt, dT, d6, wdT, wd6, s0, s1)
     return xt, saved
 
@@ -252,10 +260,14 @@ def decoder_backward(dxt, saved, P: DecoderParams, need_dz: bool = True, dxt_is_
     r1, u, a, m, i, xt, dT, d6, wdT, wd6, s0, s1 = saved
     o = gout if gout is not None else [None] * 22
     dpre = dxt if dxt_is_pre_tanh else ops.tanh_backward(dxt, xt)
-    dw6, db6 = ops.conv_wgrad(d6, a, dpre, P.convt6.weight.shape, dw=o[20], dbias=o[21])
-    da = ops.conv_dgrad(d6, dpre, wd6)
     dbT = o[17] if o[17] is not None else torch.empty(u.shape[-1], dtype=torch.float32, device=u.device)
-    du, dg4, dbe4 = ops.bn_backward(u, None, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19], dx_colsum=dbT, relu_beta=P.bn4.bias)
+    if a is None:       # fused output layer: BatchNorm backward, the transposed conv's data and weight gradients in two passes over u
+        du, dw6, db6, dg4, dbe4 = ops.bn_relu_c1convt_backward(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, dpre, dw=o[20],
+                                                               dbias=o[21], dgamma=o[18], dbeta=o[19], du_colsum=dbT)
+    else:
+        dw6, db6 = ops.conv_wgrad(d6, a, dpre, P.convt6.weight.shape, dw=o[20], dbias=o[21])
+        da = ops.conv_dgrad(d6, dpre, wd6)
+        du, dg4, dbe4 = ops.bn_backward(u, None, da, m, i, P.bn4.weight, dgamma=o[18], dbeta=o[19], dx_colsum=dbT, relu_beta=P.bn4.bias)
     dwT, _ = ops.conv_wgrad(dT, r1, du, P.convt3.weight.shape, dw=o[16], want_bias=False)   # r1 is stored ReLU'd
     dr1 = ops.conv_dgrad(dT, du, wdT, relu_x=r1)               # decoder.2 ReLU's mask applied in the dgrad store
     dr0, g1 = resblock_backward(dr1, s1, P.res1, gout=o[8:16] if gout is not None else None)

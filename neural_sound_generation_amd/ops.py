@@ -415,6 +415,48 @@ def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None
 
 
 # ------------------------------------------------------------------------------------------------
+# decoder.4-7 as one operator: BatchNorm2d -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) [-> Tanh]   (src/models.py:180-183)
+# ------------------------------------------------------------------------------------------------
+def bn_relu_c1convt_supported(dtype, C) -> bool:
+    return bool(_lib.query("nsg_bn_relu_c1convt_supported", c_int32(nsg_dtype(dtype)), c_int32(C)))
+
+
+def bn_relu_c1convt_forward(u, mean, invstd, gamma, beta, w, bias, tanh=True):
+    """u NHWC (B, H, W, C) = the BatchNorm input; w the ConvTranspose2d parameter (C, 1, 4, 4) fp32.  Returns the fp32 image
+    (B, 2H, 2W, 1).  relu(bn(u)) is never stored (nsg.h: nsg_bn_relu_c1convt_forward)."""
+    _chk(u, "u", None); _chk(w, "w", torch.float32)
+    B, H, W, C = u.shape
+    y = torch.empty((B, 2 * H, 2 * W, 1), dtype=torch.float32, device=u.device)
+    nb = _lib.query("nsg_bn_relu_c1convt_workspace_bytes", c_int32(B), c_int32(H), c_int32(W), c_int32(C))
+    ws = WS.get(nb, u.device)
+    _lib.call("nsg_bn_relu_c1convt_forward", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias),
+              _p(y), c_int32(NSG_TANH_OUT if tanh else 0), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws), c_size_t(nb), _stream())
+    return y
+
+
+def bn_relu_c1convt_backward(u, mean, invstd, gamma, beta, w, dy, dw=None, dbias=None, dgamma=None, dbeta=None, du_colsum=None):
+    """dy: fp32 gradient image (B, 2H, 2W[, 1]) w.r.t. the transposed conv's output (before the tanh).
+    Returns (du like u, dw (C, 1, 4, 4), dbias (1,), dgamma, dbeta); du_colsum: optional [C] tensor receiving the column
+    sums of du (the bias gradient of the conv in front of the BatchNorm)."""
+    _chk(u, "u", None); _chk(w, "w", torch.float32); _chk(dy, "dy", torch.float32)
+    B, H, W, C = u.shape
+    if dy.numel() != B * 4 * H * W:
+        raise ValueError("bn_relu_c1convt_backward: dy does not match (B, 2H, 2W)")
+    dev = u.device
+    du = torch.empty_like(u)
+    dw = dw if dw is not None else torch.empty_like(w)
+    dbias = dbias if dbias is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    dgamma = dgamma if dgamma is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    nb = _lib.query("nsg_bn_relu_c1convt_workspace_bytes", c_int32(B), c_int32(H), c_int32(W), c_int32(C))
+    ws = WS.get(nb, dev)
+    _lib.call("nsg_bn_relu_c1convt_backward", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(dy),
+              _p(du), _p(du_colsum), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws),
+              c_size_t(nb), _stream())
+    return du, dw, dbias, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
 # element-wise / losses / optimiser
 # ------------------------------------------------------------------------------------------------
 def relu_backward_add(a, b, x, out=None):

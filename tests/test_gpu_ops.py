@@ -520,6 +520,51 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
         _close(dw.cpu(), dw2.cpu(), tol=2e-5, what="dw vs unfused")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 32), (3, 40, 64, 128), (2, 10, 130, 96), (1, 3, 70, 64), (2, 5, 150, 128)])
+def test_bn_relu_c1convt_fused_output_layer(B, H, W, C):
+    """decoder.4-7 (BatchNorm2d -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) -> Tanh, src/models.py:180-183) as one operator on bf16
+    tensors, against CPU PyTorch autograd on the same bf16-rounded input.  The operator rounds relu(bn(u)) and the conv
+    weights to bf16 on their way into the MFMA (as the separate bf16 operators do) and stores du as bf16: 1e-2 of the largest
+    reference value; the image-sized outputs see the bf16 products averaged over C channels: 4e-3."""
+    g = torch.Generator().manual_seed(B * 100 + C + W)
+    u = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.5).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(C, 1, 4, 4, generator=g) * 0.2).requires_grad_(True)
+    b = (torch.randn(1, generator=g) * 0.1).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.3).requires_grad_(True)
+    pre = F.conv_transpose2d(F.relu(F.batch_norm(u, None, None, gamma, beta, True, 0.1, 1e-5)), w, b, 2, 1)
+    dy = torch.randn(pre.shape, generator=g)
+    gu, gw, gb, gg, gbe = torch.autograd.grad(pre, [u, w, b, gamma, beta], dy)
+
+    ug = gpu(nhwc(u.detach())).bfloat16()
+    assert ops.bn_relu_c1convt_supported(torch.bfloat16, C) and not ops.bn_relu_c1convt_supported(torch.float32, C)
+    mean, invstd = ops.bn_stats(ug, C, None, None)
+    wg, bg, gag, beg = gpu(w.detach()), gpu(b.detach()), gpu(gamma.detach()), gpu(beta.detach())
+    y_pre = ops.bn_relu_c1convt_forward(ug, mean, invstd, gag, beg, wg, bg, tanh=False)
+    _close(nchw(y_pre.cpu()), pre.detach(), tol=4e-3, what="fused output layer forward")
+    y_t = ops.bn_relu_c1convt_forward(ug, mean, invstd, gag, beg, wg, bg, tanh=True)
+    assert torch.equal(y_t, torch.tanh(y_pre)) or float((y_t - torch.tanh(y_pre)).abs().max()) <= 2e-6
+    dyg = gpu(dy.view(B, 2 * H, 2 * W))
+    cs = torch.empty(C, device=DEV)
+    du, dw, dbias, dgm, dbt = ops.bn_relu_c1convt_backward(ug, mean, invstd, gag, beg, wg, dyg, du_colsum=cs)
+    # column sums of du (bias gradient of the conv in front of the BatchNorm; mathematically zero): against the fp32 values
+    # before du's bf16 rounding -- bounded by the rounding of the stored du
+    assert float((cs.cpu() - du.float().sum(dim=(0, 1, 2)).cpu()).abs().max()) <= 2e-2 * float(du.float().abs().sum(dim=(0, 1, 2)).max())
+    _close(nchw(du.float().cpu()), gu, tol=1e-2, what="fused output layer du")
+    _close(dw.cpu(), gw, tol=1e-2, what="fused output layer dw")
+    _close(dgm.cpu(), gg, tol=1e-2, what="fused output layer dgamma")
+    _close(dbt.cpu(), gbe, tol=1e-2, what="fused output layer dbeta")
+    _close(dbias.cpu(), gb, tol=1e-5, what="fused output layer dbias")
+    # against the separate operators of this library on the same tensors (they store a and da as bf16): same tolerance class
+    d6 = ops.conv_desc(B, H, W, C, 1, 4, 2, 1, transposed=True, dtype=torch.bfloat16)
+    wf6, wd6 = ops.pack_weights(d6, wg)
+    a = ops.bn_apply(ug, mean, invstd, gag, beg, relu=True)
+    y2 = ops.conv_forward(d6, a, wf6, bg, flags=0)
+    _close(y_pre.cpu(), y2.cpu(), tol=2e-3, what="forward vs separate operators")
+    dw2, _ = ops.conv_wgrad(d6, a, dyg.view(B, 2 * H, 2 * W, 1), (C, 1, 4, 4))
+    _close(dw.cpu(), dw2.cpu(), tol=2e-3, what="dw vs separate operators")
+
+
 def test_batchnorm_eval():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 16, 6, 5, generator=g)
