@@ -106,11 +106,14 @@ NSG_API int nsg_vq_forward(const float *x, const float *e, int64_t N, int32_t D,
 /* The same search for the bf16 compute mode: the contraction runs on the bf16 matrix pipe with both fp32 operands
  * split into bf16 hi + lo parts (3 MFMAs per 16 channels, fp32 accumulate): distances carry a relative error of
  * ~2^-16, so on near-ties the chosen code may differ from the reference's (NOT the bit-exact search; the fp32
- * parity mode uses nsg_vq_forward).  D % 8 == 0.  Workspace: nsg_vq_bf16x3_workspace_bytes. */
+ * parity mode uses nsg_vq_forward).  D % 8 == 0.  Workspace: nsg_vq_bf16x3_workspace_bytes.
+ * codes_bf16_out (or NULL): the chosen code rows as bf16 [N][D], with max(0, .) applied when bf16_relu != 0 -- the
+ * decoder's input after its leading ReLU (models.py:176) in the bf16 mode, written here instead of by a separate
+ * conversion pass over an fp32 copy (codes_out may then be NULL: nsg_vq_losses_indexed reads the codebook itself). */
 NSG_API size_t nsg_vq_bf16x3_workspace_bytes(int64_t N, int32_t D, int32_t K);
 NSG_API int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
-                                  float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes,
-                                  void *stream);
+                                  float *codes_out, float *dmin_out, void *codes_bf16_out, int32_t bf16_relu, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 
 /* out[r] = torch.sum(v[r]**2) with ATen's CPU summation order (vector_quantization.py:12-13). */
 NSG_API int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream);
@@ -336,6 +339,13 @@ NSG_API int nsg_mse_padded(const float *a, const float *c, int64_t rows, int32_t
 NSG_API int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_scale, float dq_scale,
                           const void *dz_add, float *loss_out, void *dz, float *dq, int32_t grad_dtype,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same loss and encoder-side gradient with q given by (codebook [K][D], idx [N]): q[r] = codebook[idx[r]] is read from
+ * the cache-resident codebook instead of a materialised tensor (D % 8 == 0).  The codebook-side gradient of the loss is
+ * 2/n * (n_k e_k - sum of the rows assigned to k): nsg_index_add_rows over z with counts (train.py:131). */
+NSG_API int nsg_vq_losses_indexed(const float *z, const float *codebook, const int64_t *idx, int64_t N, int32_t D, int32_t K,
+                                  float dz_scale, const void *dz_add, float *loss_out, void *dz, int32_t grad_dtype,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* torch.optim.Adam step (src/main.py:124 defaults, no weight decay, no amsgrad) over one flat
  * fp32 buffer.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce).

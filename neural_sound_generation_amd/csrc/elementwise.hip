@@ -190,6 +190,43 @@ __global__ __launch_bounds__(256) void vq_losses_kernel(const float *__restrict_
     block_sum_store(acc, partial);
 }
 
+// The same loss and encoder-side gradient with q given as (codebook, indices): q[row] = e[idx[row]] is read from the
+// L2-resident codebook instead of a materialised [N][D] tensor.  D % 8 == 0; a thread takes 8 channels of one row.
+template <typename TG>
+__global__ __launch_bounds__(256) void vq_losses_indexed_kernel(const float *__restrict__ z, const float *__restrict__ e,
+                                                                const int64_t *__restrict__ idx, int64_t N, int D, int K, float zscale,
+                                                                const TG *__restrict__ dz_add, TG *__restrict__ dz, double *partial)
+{
+    const int D8 = D >> 3;
+    const int64_t nv = N * D8;
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / D8;
+        const int d8 = (int)(i - row * D8) * 8;
+        int64_t k = idx[row];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);                 // (validated indices; clamped so a bad one cannot fault)
+        float zv[8], qv[8], g[8];
+        ldw<float, 8>(z + i * 8, zv);
+        ldw<float, 8>(e + (size_t)k * D + d8, qv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float d = zv[c] - qv[c];
+            acc += (double)(d * d);
+            g[c] = d * zscale;
+        }
+        if (dz) {
+            if (dz_add) {
+                float av[8];
+                ldw<TG, 8>(dz_add + i * 8, av);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) g[c] += av[c];
+            }
+            stw<TG, 8>(dz + i * 8, g);
+        }
+    }
+    block_sum_store(acc, partial);
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, int64_t nv, float b1, float b2,
                                                    float eps, float step_size, float bc2_sqrt, float gscale)
@@ -430,6 +467,30 @@ int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_scale, flo
 #undef NSG_VQL
     hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, s, partial, nb, (double)n, loss_out);
     return nsg_check_launch("vq_losses");
+}
+
+int nsg_vq_losses_indexed(const float *z, const float *codebook, const int64_t *idx, int64_t N, int32_t D, int32_t K, float dz_scale,
+                          const void *dz_add, float *loss_out, void *dz, int32_t grad_dtype, void *workspace, size_t workspace_bytes,
+                          void *stream)
+{
+    NSG_REQUIRE(z && codebook && idx && loss_out && N > 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_vq_losses_indexed: bad argument");
+    NSG_REQUIRE(D % 8 == 0, NSG_E_UNSUPPORTED, "nsg_vq_losses_indexed: D=%d must be a multiple of 8", D);
+    NSG_REQUIRE(grad_dtype == NSG_F32 || grad_dtype == NSG_BF16, NSG_E_INVALID, "nsg_vq_losses_indexed: grad_dtype must be NSG_F32 or NSG_BF16");
+    NSG_REQUIRE(nsg_aligned16(z) && nsg_aligned16(codebook) && (!dz || nsg_aligned16(dz)) && (!dz_add || nsg_aligned16(dz_add)), NSG_E_INVALID,
+                "nsg_vq_losses_indexed: pointers must be 16-byte aligned");
+    const int64_t n = N * D;
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_reduce_workspace_bytes(n), NSG_E_WORKSPACE, "nsg_vq_losses_indexed: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = reinterpret_cast<double *>(workspace);
+    const float zs = dz_scale * 2.0f / (float)n;
+    int nb = ew_blocks(n / 8);
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (grad_dtype == NSG_BF16)
+        hipLaunchKernelGGL((vq_losses_indexed_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const bf16_t *)dz_add, (bf16_t *)dz, partial);
+    else
+        hipLaunchKernelGGL((vq_losses_indexed_kernel<float>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const float *)dz_add, (float *)dz, partial);
+    hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, s, partial, nb, (double)n, loss_out);
+    return nsg_check_launch("vq_losses_indexed");
 }
 
 int nsg_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,

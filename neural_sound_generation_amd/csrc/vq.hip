@@ -291,11 +291,25 @@ __global__ void gather_rows_kernel(const float *__restrict__ e, const int64_t *_
     }
 }
 
-__global__ void count_codes_kernel(const int64_t *idx, int64_t N, int K, int *counts)
+// Histogram of the indices: per-block bins in LDS (integer adds: order-free, exact), one global add per non-empty bin and
+// block.  (Global atomics straight from every row serialise on the few hundred hot bins: 650 us for 655k rows.)
+constexpr int COUNT_LDS_BINS = 8192;
+__global__ __launch_bounds__(256) void count_codes_kernel(const int64_t *__restrict__ idx, int64_t N, int K, int *__restrict__ counts)
 {
+    extern __shared__ int bins[];
+    const bool lds = K <= COUNT_LDS_BINS;
+    if (lds) {
+        for (int k = threadIdx.x; k < K; k += 256) bins[k] = 0;
+        __syncthreads();
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t k = idx[i];
-        if (k >= 0 && k < K) atomicAdd(&counts[k], 1);
+        if (k >= 0 && k < K) atomicAdd(lds ? &bins[k] : &counts[k], 1);
+    }
+    if (lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += 256)
+            if (bins[k]) atomicAdd(&counts[k], bins[k]);
     }
 }
 __global__ void counts_to_float_kernel(const int *counts, int K, float *out)
@@ -467,8 +481,8 @@ static int index_add_impl(int onehot_mode, const int64_t *idx, const float *g, i
         int *cnt = reinterpret_cast<int *>(workspace);
         hipError_t err = hipMemsetAsync(cnt, 0, (size_t)K * sizeof(int), s);
         if (err != hipSuccess) return nsg_fail((int)err, "nsg_index_add_rows: memset failed");
-        const int nb = (int)(nsg_cdiv(N, 256) > 1024 ? 1024 : nsg_cdiv(N, 256));
-        hipLaunchKernelGGL(count_codes_kernel, dim3(nb), dim3(256), 0, s, idx, N, K, cnt);
+        const int nb = (int)(nsg_cdiv(N, 1024) > 256 ? 256 : nsg_cdiv(N, 1024));
+        hipLaunchKernelGGL(count_codes_kernel, dim3(nb), dim3(256), K <= COUNT_LDS_BINS ? (size_t)K * sizeof(int) : 0, s, idx, N, K, cnt);
         hipLaunchKernelGGL(counts_to_float_kernel, dim3((K + 255) / 256), dim3(256), 0, s, cnt, K, counts_out);
         int rc = nsg_check_launch("count_codes_kernel");
         if (rc) return rc;

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
                                                                 const bf16_t *__restrict__ elo, const float *__restrict__ e,
                                                                 const float *__restrict__ x2, const float *__restrict__ c2,
                                                                 int64_t N, int D, int K, int64_t *__restrict__ idx_out,
-                                                                float *__restrict__ codes_out, float *__restrict__ dmin_out)
+                                                                float *__restrict__ codes_out, float *__restrict__ dmin_out,
+                                                                bf16_t *__restrict__ codes_lp_out, int lp_relu)
 {
     constexpr int DP = 16 * NKS;
     constexpr int EPB = DP * 2 + 16;              // LDS row pitch in bytes: 16 rows -> 16 different 16-byte slots
@@ -166,20 +167,39 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
             }
         }
     }
-    if (codes_out == nullptr) return;
+    if (codes_out == nullptr && codes_lp_out == nullptr) return;
     __syncthreads();
     // ---- gather the (fp32) code rows: codes_out[row] = e[idx[row]] ----
-    const int D4 = D >> 2;
-    for (int f = tid; f < 128 * D4; f += 256) {
-        const int r = f / D4, d4 = (f - r * D4) * 4;
-        const int64_t row = row0 + r;
-        if (row < N) *reinterpret_cast<v4f *>(codes_out + row * D + d4) = *reinterpret_cast<const v4f *>(e + (size_t)sidx[r] * D + d4);
+    if (codes_out) {
+        const int D4 = D >> 2;
+        for (int f = tid; f < 128 * D4; f += 256) {
+            const int r = f / D4, d4 = (f - r * D4) * 4;
+            const int64_t row = row0 + r;
+            if (row < N) *reinterpret_cast<v4f *>(codes_out + row * D + d4) = *reinterpret_cast<const v4f *>(e + (size_t)sidx[r] * D + d4);
+        }
+    }
+    // ---- and / or their bf16 copy, optionally ReLU'd: what the decoder's leading ReLU consumes in the bf16 mode ----
+    if (codes_lp_out) {
+        const int D8 = D >> 3;
+        for (int f = tid; f < 128 * D8; f += 256) {
+            const int r = f / D8, d8 = (f - r * D8) * 8;
+            const int64_t row = row0 + r;
+            if (row >= N) continue;
+            const float *src = e + (size_t)sidx[r] * D + d8;
+            const v4f a = *reinterpret_cast<const v4f *>(src), b = *reinterpret_cast<const v4f *>(src + 4);
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (lp_relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            Elem<bf16_t>::store16(codes_lp_out + row * D + d8, v);
+        }
     }
 }
 
 template <int NKS>
 int launch(const float *x, const bf16_t *ehi, const bf16_t *elo, const float *e, const float *x2, const float *c2, int64_t N, int D,
-           int K, int64_t *idx, float *codes, float *dmin, hipStream_t s)
+           int K, int64_t *idx, float *codes, float *dmin, bf16_t *codes_lp, int lp_relu, hipStream_t s)
 {
     constexpr int DP = 16 * NKS;
     const size_t lds = (size_t)2 * 2 * 32 * (DP * 2 + 16);
@@ -192,7 +212,7 @@ int launch(const float *x, const bf16_t *ehi, const bf16_t *elo, const float *e,
         if (er != hipSuccess) return nsg_fail((int)er, "vq_forward_bf16x3: cannot reserve %zu bytes of LDS", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin);
+    hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
     return nsg_check_launch("vq_forward_bf16x3_kernel");
 }
 
@@ -210,12 +230,13 @@ size_t nsg_vq_bf16x3_workspace_bytes(int64_t N, int32_t D, int32_t K)
 }
 
 int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out, float *codes_out,
-                          float *dmin_out, void *workspace, size_t workspace_bytes, void *stream)
+                          float *dmin_out, void *codes_bf16_out, int32_t bf16_relu, void *workspace, size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(x && e && idx_out && N >= 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_vq_forward_bf16x3: bad argument");
     NSG_REQUIRE(D <= 256 && D % 8 == 0, NSG_E_UNSUPPORTED, "nsg_vq_forward_bf16x3: D=%d must be a multiple of 8, at most 256", D);
-    NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(e) && (!codes_out || nsg_aligned16(codes_out)), NSG_E_INVALID,
-                "nsg_vq_forward_bf16x3: pointers must be 16-byte aligned");
+    NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(e) && (!codes_out || nsg_aligned16(codes_out)) && (!codes_bf16_out || nsg_aligned16(codes_bf16_out)),
+                NSG_E_INVALID, "nsg_vq_forward_bf16x3: pointers must be 16-byte aligned");
+    bf16_t *lp = reinterpret_cast<bf16_t *>(codes_bf16_out);
     if (N == 0) return NSG_OK;
     NSG_REQUIRE(workspace && workspace_bytes >= nsg_vq_bf16x3_workspace_bytes(N, D, K), NSG_E_WORKSPACE,
                 "nsg_vq_forward_bf16x3: workspace too small");
@@ -236,11 +257,11 @@ int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, 
     rc = nsg_check_launch("split_bf16_kernel");
     if (rc) return rc;
     switch (DP) {
-    case 16:  return launch<1>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    case 32:  return launch<2>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    case 64:  return launch<4>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    case 128: return launch<8>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    default:  return launch<16>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+    case 16:  return launch<1>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
+    case 32:  return launch<2>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
+    case 64:  return launch<4>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
+    case 128: return launch<8>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
+    default:  return launch<16>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
     }
 }
 

@@ -232,10 +232,12 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
 # ------------------------------------------------------------------------------------------------
 # Decoder   (src/models.py:175-184)
 # ------------------------------------------------------------------------------------------------
-def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None):
-    """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype."""
+def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None, zq_is_relu=False):
+    """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype.
+    zq_is_relu: zq already holds max(0, z_q) in `dtype` (the quantiser wrote it: ops.vq_forward codes_bf16="relu")."""
     B, H, W, D = zq.shape
-    zq = ops.convert(zq, dtype, relu=True)                       # decoder.0's leading ReLU, applied once here
+    if not (zq_is_relu and zq.dtype == dtype):
+        zq = ops.convert(zq, dtype, relu=True)                   # decoder.0's leading ReLU, applied once here
     pk = packs if packs is not None else {}
     r0, s0 = resblock_forward(zq, P.res0, training, relu_out=True, packs=pk.get("res0"))
     r1, s1 = resblock_forward(r0, P.res1, training, relu_out=True, packs=pk.get("res1"))   # decoder.2 ReLU applied at the producer

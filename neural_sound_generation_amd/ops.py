@@ -106,10 +106,12 @@ def _gemm_flops(d: "ConvDesc") -> float:
 # ------------------------------------------------------------------------------------------------
 # vector quantiser
 # ------------------------------------------------------------------------------------------------
-def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma"):
+def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", codes_bf16=None):
     """x2d (N,D), codebook (K,D) -> idx (N,) int64 [, codes (N,D)] [, dmin (N,)]
     impl: "mfma" = the bit-exact fp32 search (parity mode); "valu" = its vector-ALU cross-check; "bf16x3" = the bf16
-    mode's search on the bf16 matrix pipe with split operands (relative distance error ~2^-16: near-ties may differ)."""
+    mode's search on the bf16 matrix pipe with split operands (relative distance error ~2^-16: near-ties may differ).
+    codes_bf16 ("plain" | "relu", bf16x3 only): also return the code rows as a bf16 (N,D) tensor (ReLU'd: the decoder's
+    input after its leading ReLU) as a 4th result."""
     _chk(x2d, "x"); _chk(codebook, "codebook")
     N, D = x2d.shape
     K, D2 = codebook.shape
@@ -123,8 +125,19 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma"):
         nb = _lib.query(wsfn, c_int64(N), c_int32(D), c_int32(K))
         ws = WS.get(nb, x2d.device)
         fn = {"mfma": "nsg_vq_forward", "valu": "nsg_debug_vq_forward_valu", "bf16x3": "nsg_vq_forward_bf16x3"}[impl]
+        if impl == "bf16x3":
+            lp = torch.empty(N, D, dtype=torch.bfloat16, device=x2d.device) if codes_bf16 else None
+            _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin), _p(lp),
+                      c_int32(1 if codes_bf16 == "relu" else 0), _p(ws), c_size_t(nb), _stream())
+            if codes_bf16:
+                return idx, codes, dmin, lp
+            return idx, codes, dmin
+        if codes_bf16:
+            raise ValueError("vq_forward: codes_bf16 needs impl='bf16x3'")
         _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin),
                   _p(ws), c_size_t(nb), _stream())
+    elif codes_bf16:
+        return idx, codes, dmin, torch.empty(0, D, dtype=torch.bfloat16, device=x2d.device)
     return idx, codes, dmin
 
 
@@ -539,6 +552,21 @@ def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_
     _lib.call("nsg_vq_losses", _p(z), _p(q), c_int64(n), c_float(dz_scale), c_float(dq_scale), _p(dz_add), _p(loss), _p(dz),
               _p(dq), c_int32(nsg_dtype(grad_dtype)), _p(ws), c_size_t(nb), _stream())
     return loss, dz, dq
+
+
+def vq_losses_indexed(z2d, codebook, idx, dz_scale=1.0, dz_add=None, want_dz=True, grad_dtype=torch.float32):
+    """vq_losses with q = codebook[idx] read from the codebook itself: returns (loss, dz).  z2d (N, D) fp32."""
+    _chk(z2d, "z"); _chk(codebook, "codebook"); _chk(idx, "idx", torch.int64)
+    if dz_add is not None:
+        _chk(dz_add, "dz_add", grad_dtype)
+    N, D = z2d.shape
+    loss = torch.empty(1, dtype=torch.float32, device=z2d.device)
+    dz = torch.empty(z2d.shape, dtype=grad_dtype, device=z2d.device) if want_dz else None
+    nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(N * D))
+    ws = WS.get(nb, z2d.device)
+    _lib.call("nsg_vq_losses_indexed", _p(z2d), _p(codebook), _p(idx), c_int64(N), c_int32(D), c_int32(codebook.shape[0]), c_float(dz_scale),
+              _p(dz_add), _p(loss), _p(dz), c_int32(nsg_dtype(grad_dtype)), _p(ws), c_size_t(nb), _stream())
+    return loss, dz
 
 
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

@@ -63,14 +63,22 @@ class FusedTrainStep:
         ze, es = engine.encoder_forward(x, self.encP, True, dtype=self.dtype, packs=enc_packs)
         D = ze.shape[-1]
         K = self.codebook.shape[0]
-        idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True,
-                                    impl=getattr(self.model.codebook, "search_impl", "mfma"))
-        zq = zq.view_as(ze)
-        zdec = zq
+        search = getattr(self.model.codebook, "search_impl", "mfma")
+        # bf16 mode without speaker conditioning: z_q is never materialised in fp32 -- the search writes the decoder's
+        # (ReLU'd, bf16) input itself, the losses read codebook[idx], the codebook gradient comes from per-code sums of z_e
+        lean = search == "bf16x3" and self.dtype == torch.bfloat16 and self.spk is None and D % 8 == 0
+        if lean:
+            idx, _, _, zdec = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=False, impl=search, codes_bf16="relu")
+            zq = None
+            zdec = zdec.view(ze.shape)
+        else:
+            idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True, impl=search)
+            zq = zq.view_as(ze)
+            zdec = zq
         if self.spk is not None and g is not None:
             g = g.view(-1).to(torch.int64).contiguous()
             zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g), out_dtype=self.dtype)
-        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs)
+        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs, zq_is_relu=lean)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
         loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
         dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)
@@ -82,7 +90,17 @@ class FusedTrainStep:
                 self.g_spk.zero_()
         # loss_vq = mse(z_q, sg(z_e)) -> codebook; loss_commit = mse(z_e, sg(z_q)) -> encoder,
         # plus the straight-through gradient from the decoder               (train.py:131-134)
-        if self.ema:
+        if lean:
+            loss_vq, dz = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
+                                                grad_dtype=self.dtype)
+            dz = dz.view(ze.shape)
+            s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
+            if self.ema:
+                self.ema_stats = torch.cat([n, s.view(-1)])
+            else:   # d loss_vq / d e_k = 2/numel * sum over the rows assigned to k of (e_k - z) = 2/numel * (n_k e_k - s_k)
+                torch.mul(self.codebook.detach(), n.unsqueeze(1), out=self.g_code.view(K, D))
+                self.g_code.view(K, D).sub_(s).mul_(2.0 / ze.numel())
+        elif self.ema:
             # EMA codebook (extension): no codebook gradient; per-code counts and sums of the assigned
             # encoder rows are the statistics every rank contributes (summed over ranks in step())
             loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False, grad_dtype=self.dtype)

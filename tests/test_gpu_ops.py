@@ -145,6 +145,32 @@ def test_index_add_rows_bf16x2(N, D, K):
     assert torch.equal(got, got2), "must be bitwise reproducible"
 
 
+def test_vq_lean_path_pieces():
+    """The bf16 mode's quantiser without an fp32 copy of z_q: the search's bf16 (ReLU'd) code rows, the losses with q read
+    from the codebook through the indices, and the codebook gradient from per-code sums -- each against the materialised
+    form (bit-identical loss and dz: the same arithmetic on the same values)."""
+    g = torch.Generator().manual_seed(11)
+    N, D, K = 5000, 128, 512
+    z = gpu(torch.randn(N, D, generator=g))
+    e = gpu(torch.randn(K, D, generator=g) * 0.8)
+    idx, codes, _, lp = ops.vq_forward(z, e, want_codes=True, impl="bf16x3", codes_bf16="relu")
+    assert torch.equal(codes, e[idx])
+    assert torch.equal(lp, torch.relu(codes).bfloat16())
+    _, _, _, lp2 = ops.vq_forward(z, e, want_codes=False, impl="bf16x3", codes_bf16="plain")
+    assert torch.equal(lp2, codes.bfloat16())
+    add = gpu(torch.randn(N, D, generator=g)).bfloat16()
+    for gd, a in ((torch.float32, None), (torch.bfloat16, add)):
+        loss1, dz1, dq1 = ops.vq_losses(z, codes, dz_scale=0.25, dq_scale=1.0, dz_add=a, grad_dtype=gd)
+        loss2, dz2 = ops.vq_losses_indexed(z, e, idx, dz_scale=0.25, dz_add=a, grad_dtype=gd)
+        assert torch.equal(dz1, dz2)
+        assert abs(float(loss1) - float(loss2)) <= 1e-6 * abs(float(loss1))
+    # codebook gradient: 2/numel * (n_k e_k - s_k) against the scatter of dq (1e-5 of the largest entry)
+    want = ops.index_add_rows(idx, dq1, K)
+    s_, n_ = ops.index_add_rows(idx, z, K, want_counts=True)
+    got = (e * n_.unsqueeze(1) - s_) * (2.0 / z.numel())
+    _close(got.cpu(), want.cpu(), tol=1e-5, what="codebook gradient from per-code sums")
+
+
 def test_vq_operator_surface(golden_dir):
     g = golden(golden_dir, "vq_ops.npz")
     x = gpu(torch.from_numpy(g["st.x"])).requires_grad_(True)
