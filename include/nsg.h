@@ -297,6 +297,36 @@ NSG_API int nsg_bn_relu_c1convt_backward(const void *u, int32_t dtype, const flo
                                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The ResBlock's 1x1 convolution with the BatchNorm work around it folded in     src/models.py:151-155
+ *   ... BatchNorm2d(dim) -> ReLU(True) -> Conv2d(dim, dim, 1) -> BatchNorm2d(dim)
+ * A 1x1 conv over NHWC rows is a flat GEMM [M][C] x [C][C]: a stream kernel.  These entry points apply the
+ * BatchNorm arithmetic of the neighbouring layers on the operand's way from the global-load registers into LDS,
+ * so the activated tensor relu(bn(x)) is never stored and the second BatchNorm's input gradient is produced and
+ * consumed in one pass.  bf16 tensors, C = 32, 64, 128 (nsg_bn_relu_conv1x1_supported); w: (C, C, 1, 1) fp32.
+ * ------------------------------------------------------------------------------------------- */
+NSG_API int32_t nsg_bn_relu_conv1x1_supported(int32_t dtype, int32_t C);
+NSG_API size_t nsg_bn_relu_conv1x1_workspace_bytes(int64_t M, int32_t C);
+/* y = relu((x - mean) * invstd * gamma + beta) * w^T + bias          (replaces nsg_bn_apply + nsg_conv_forward) */
+NSG_API int nsg_bn_relu_conv1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                        const float *w, const float *bias, void *y, int64_t M, int32_t C, int32_t dtype,
+                                        void *workspace, size_t workspace_bytes, void *stream);
+/* dw[o][i] = sum_m dy[m][o] * relu(bn(x))[m][i]                        (nsg_conv_wgrad with the activation rebuilt from x) */
+NSG_API int nsg_bn_relu_conv1x1_wgrad(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                      const void *dy, float *dw, int64_t M, int32_t C, int32_t dtype, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+/* The apply half of nsg_bn_backward (no ReLU; dgamma / dbeta from nsg_bn_backward_sums) fused with the data gradient of
+ * the 1x1 conv in FRONT of that BatchNorm:  dh = bn-backward(dy) at input h (stored: the weight gradient needs it),
+ * dx = dh * w, dh_colsum [C] or NULL = column sums of dh (the conv's bias gradient). */
+NSG_API int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma,
+                                          const float *dgamma, const float *dbeta, const float *w, void *dh, void *dx,
+                                          float *dh_colsum, int64_t M, int32_t C, int32_t dtype, void *workspace,
+                                          size_t workspace_bytes, void *stream);
+/* The reduction half of nsg_bn_backward alone (same arguments, same values): dgamma, dbeta. */
+NSG_API int nsg_bn_backward_sums(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd,
+                                 const float *gamma, const float *relu_beta, float *dgamma, float *dbeta, int64_t M, int32_t C,
+                                 int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Element-wise, losses, optimiser                         src/train.py:118-136
  * ------------------------------------------------------------------------------------------- */
 

@@ -72,6 +72,12 @@ _SIGS = {
     "nsg_bn_relu_c1convt_forward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_bn_relu_c1convt_backward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
                                             c_size_t, _P]),
+    "nsg_bn_relu_conv1x1_supported": (c_int32, [c_int32, c_int32]),
+    "nsg_bn_relu_conv1x1_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "nsg_bn_relu_conv1x1_forward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_relu_conv1x1_wgrad": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_backward_conv1x1_dgrad": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_backward_sums": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, c_int32, _P]),
     "nsg_convert": (None, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     "nsg_tanh_backward": (None, [_P, _P, _P, c_int64, _P]),

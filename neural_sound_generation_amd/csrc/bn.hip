@@ -442,6 +442,13 @@ int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamm
     return nsg_check_launch("bn_bwd_final_kernel");
 }
 
+int nsg_launch_slab_sum_final(const float *partial, int nslab, int C, float *out, hipStream_t s)
+{
+    if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "slab_sum_final: %d slabs / %d channels not supported", nslab, C);
+    hipLaunchKernelGGL(slab_sum_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, nslab, C, out);
+    return nsg_check_launch("slab_sum_final_kernel");
+}
+
 extern "C" {
 
 size_t nsg_bn_workspace_bytes(int64_t M, int32_t C)
@@ -544,6 +551,31 @@ int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const flo
     }
     if (dx_colsum) hipLaunchKernelGGL(slab_sum_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dx_colsum);
     return nsg_check_launch("bn_backward");
+}
+
+/* The reduction half of nsg_bn_backward alone: dgamma, dbeta (what a fused consumer of the apply half needs first). */
+int nsg_bn_backward_sums(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd, const float *gamma,
+                         const float *relu_beta, float *dgamma, float *dbeta, int64_t M, int32_t C, int32_t dtype, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta, NSG_E_INVALID, "nsg_bn_backward_sums: null pointer");
+    int rc = check_mc("nsg_bn_backward_sums", M, C, dtype);
+    if (rc) return rc;
+    NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(dy) && (!y_relu || nsg_aligned16(y_relu)), NSG_E_INVALID,
+                "nsg_bn_backward_sums: pointers must be 16-byte aligned");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_bn_workspace_bytes(M, C), NSG_E_WORKSPACE, "nsg_bn_backward_sums: workspace too small");
+    const SlabGeom g = slab_geom(M);
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = reinterpret_cast<float *>(workspace);
+    if (dtype == NSG_BF16) {
+        typedef bf16_t T;
+        hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
+    } else {
+        typedef float T;
+        hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
+    }
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
+    return nsg_check_launch("bn_backward_sums");
 }
 
 }  // extern "C"

@@ -12,6 +12,13 @@ bool nsg_c1_stencil_supported(int C);
 size_t nsg_c1_stencil_wgrad_workspace_bytes(int C);
 int nsg_launch_c1_stencil_fwd(const float *img, const float *w, const float *bias, void *out, int out_dtype, int B, int LH, int LW,
                               int HH, int WW, int C, hipStream_t s);
+// gemm_flat.hip: the ResBlock's 1x1 conv as a flat GEMM with BatchNorm work in its operand staging (nsg_bn_relu_conv1x1_*)
+bool nsg_flat1x1_supported(int dtype, int C);
+size_t nsg_flat1x1_workspace_bytes(int C);
+int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
+                               const float *bias, void *y, int64_t M, int C, void *ws, hipStream_t s);
+int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
+                                const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks, hipStream_t s);
 // c1_mfma.hip / stencil_c1.hip: pieces of the fused output layer (nsg_bn_relu_c1convt_*)
 bool nsg_c1m_supported(int C);
 int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
@@ -628,6 +635,75 @@ int nsg_bn_relu_c1convt_backward(const void *u, int32_t dtype, const float *mean
     rc = nsg_launch_c1_stencil_wgrad_final(partial17, blocks, C, dw, du_colsum, s);
     if (rc) return rc;
     if (dbias) return colsum(dy, NSG_F32, (int64_t)B * 4 * H * W, 1, dbias, ws, s);
+    return NSG_OK;
+}
+
+/* ---- the ResBlock's 1x1 conv with the BatchNorm work around it folded into its operand staging (bf16, C = 32, 64, 128) ---- */
+int32_t nsg_bn_relu_conv1x1_supported(int32_t dtype, int32_t C) { return nsg_flat1x1_supported(dtype, C) ? 1 : 0; }
+
+size_t nsg_bn_relu_conv1x1_workspace_bytes(int64_t M, int32_t C)
+{
+    if (M <= 0 || C <= 0) return 0;
+    const size_t wg = nsg_align_up(nsg_wgrad_workspace_bytes(M, 1, C, C), 256);
+    const size_t fl = nsg_flat1x1_workspace_bytes(C);
+    return wg > fl ? wg : fl;
+}
+
+namespace {
+int check_1x1(const char *fn, int64_t M, int C, int dtype, size_t ws_bytes, const void *ws)
+{
+    if (!nsg_flat1x1_supported(dtype, C)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: needs bf16 tensors and C = 32, 64 or 128 (use the separate operators otherwise)", fn);
+    if (M <= 0 || M >= 0x7fffffffLL / C) return nsg_fail(NSG_E_UNSUPPORTED, "%s: M = %lld rows not supported", fn, (long long)M);
+    if (!ws || ws_bytes < nsg_bn_relu_conv1x1_workspace_bytes(M, C)) return nsg_fail(NSG_E_WORKSPACE, "%s: workspace too small", fn);
+    return NSG_OK;
+}
+}  // namespace
+
+int nsg_bn_relu_conv1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
+                                const float *bias, void *y, int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    NSG_REQUIRE(x && mean && invstd && gamma && beta && w && y, NSG_E_INVALID, "nsg_bn_relu_conv1x1_forward: null pointer");
+    int rc = check_1x1("nsg_bn_relu_conv1x1_forward", M, C, dtype, workspace_bytes, workspace);
+    if (rc) return rc;
+    NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(y) && (!bias || nsg_aligned16(bias)), NSG_E_INVALID, "nsg_bn_relu_conv1x1_forward: pointers must be 16-byte aligned");
+    return nsg_launch_flat1x1_forward(x, mean, invstd, gamma, beta, w, bias, y, M, C, workspace, (hipStream_t)stream);
+}
+
+int nsg_bn_relu_conv1x1_wgrad(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const void *dy,
+                              float *dw, int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(x && mean && invstd && gamma && beta && dy && dw, NSG_E_INVALID, "nsg_bn_relu_conv1x1_wgrad: null pointer");
+    int rc = check_1x1("nsg_bn_relu_conv1x1_wgrad", M, C, dtype, workspace_bytes, workspace);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace);
+    WgradParams p = {};
+    p.dtype = NSG_BF16;
+    p.B = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pad_w = 0;
+    p.Mp = (int)M;
+    p.P = dy; p.PH = 1; p.PW = (int)M; p.A = C;
+    p.Q = x;  p.QH = 1; p.QW = (int)M; p.C = C;
+    p.q_mean = mean; p.q_invstd = invstd; p.q_gamma = gamma; p.q_beta = beta;
+    return nsg_launch_wgrad(p, dw, ws, nsg_align_up(nsg_wgrad_workspace_bytes(M, 1, C, C), 256), s);
+}
+
+int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma,
+                                  const float *dgamma, const float *dbeta, const float *w, void *dh, void *dx, float *dh_colsum, int64_t M,
+                                  int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(h && dy && mean && invstd && gamma && dgamma && dbeta && w && dh && dx, NSG_E_INVALID, "nsg_bn_backward_conv1x1_dgrad: null pointer");
+    int rc = check_1x1("nsg_bn_backward_conv1x1_dgrad", M, C, dtype, workspace_bytes, workspace);
+    if (rc) return rc;
+    NSG_REQUIRE(nsg_aligned16(h) && nsg_aligned16(dy) && nsg_aligned16(dh) && nsg_aligned16(dx), NSG_E_INVALID,
+                "nsg_bn_backward_conv1x1_dgrad: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int nblocks = 0;
+    rc = nsg_launch_flat1x1_backward(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh, dx, M, C, workspace, &nblocks, s);
+    if (rc) return rc;
+    if (dh_colsum) {
+        return nsg_launch_slab_sum_final(reinterpret_cast<const float *>(workspace), nblocks, C, dh_colsum, s);
+    }
     return NSG_OK;
 }
 

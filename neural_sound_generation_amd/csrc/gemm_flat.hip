@@ -1,0 +1,244 @@
+// The ResBlock's 1x1 convolution (src/models.py:153, Conv2d(dim, dim, 1)) with the BatchNorm work of its neighbours folded
+// into its operand staging, bf16 mode.  A 1x1 conv over NHWC rows is a flat GEMM out[M][C] = in[M][C] * W^T with K = C <= 128:
+// 2C flops per byte moved, i.e. purely a stream kernel -- the gather / index machinery of gather_gemm buys nothing here
+// and its fixed per-tile cost is 70% of the time.  What matters is how many times the [M][C] tensors cross HBM:
+//   forward   y  = relu(bn1(x)) * W^T + b        the activated tensor a = relu(bn1(x)) is built on the way from the
+//                                                 global-load registers into LDS and never stored
+//             (nsg_bn_apply + nsg_conv_forward: read x, write a, read a, write y -> read x, write y)
+//   backward  dh = bn2-backward(dy, h)            built the same way, stored once (the weight gradient needs it), and
+//             dx = dh * W                          multiplied on the spot; the column sums of dh (the conv bias gradient) fall out
+//             (nsg_bn_backward's apply pass + nsg_conv_dgrad: read dy, h, write dh, read dh, write dx -> read dy, h, write dh, dx)
+// Block = 4 waves = one 128-row tile at a time (persistent); wave w owns rows 32w..32w+31.  MFMA (32x32x16 bf16):
+// out^T[n][row] = W[n][k] * in^T[k][row]: both operands are 16-byte row-major LDS reads (lane = W row / tile row, 8
+// consecutive k).  A lane ends up with 4 consecutive output channels of its row per register group; the tile is
+// rewritten in place in LDS (a wave only ever touches its own rows) and leaves as 16-byte coalesced stores.
+#include "nsg_common.h"
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    const v2f f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
+constexpr int ROWS = 128;
+
+struct FlatParams {
+    const bf16_t *x;        // FWD: the BatchNorm input;  BWD: the BatchNorm input h (of the BatchNorm being back-propagated)
+    const bf16_t *g;        // BWD: dy
+    const float *w;         // (C, C, 1, 1) = [out][in] fp32
+    const float *bias;      // FWD: [C] or null
+    const float *mean, *invstd, *gamma, *beta;   // the BatchNorm's statistics and parameters [C] (beta: FWD only)
+    const float *dgamma, *dbeta;                 // BWD: the BatchNorm's parameter gradients (nsg_bn_backward_sums)
+    float inv_m;                                 // BWD: 1 / M
+    bf16_t *out;            // FWD: y;  BWD: dx
+    bf16_t *mid;            // BWD: dh
+    float *colsum_partial;  // BWD: [gridDim.x][C] column sums of dh over the block's tiles (or null)
+    int64_t M;
+};
+
+// MODE 0: forward (a = max(fma(x, fs, off), 0));  MODE 1: backward (dh = fma(sc, dy, -fma(k1, h, k0)); W used transposed)
+template <int NB, int MODE>     // C = 32 NB
+__global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
+{
+    constexpr int C = 32 * NB, KS = C / 16, PITCH = C + 8, CPR = C / 8, PIECES = ROWS * CPR / 256;
+    static_assert(256 % CPR == 0, "a thread stages the same channel group in every piece");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *tile = reinterpret_cast<bf16_t *>(smem_raw);          // [ROWS][PITCH]
+    bf16_t *wt = tile + ROWS * PITCH;                             // [C (n)][PITCH (k)]
+    __shared__ __attribute__((aligned(16))) float sbias[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hb = lane >> 5;
+
+    // ---- weights -> LDS as bf16 [n][k]: FWD n = out channel, k = in channel (w[n][k]); BWD n = in channel, k = out channel (w[k][n]) ----
+    for (int i = tid; i < C * C / 2; i += 256) {
+        const int n = i / (C / 2), k = (i - n * (C / 2)) * 2;
+        const float a = MODE == 0 ? p.w[(size_t)n * C + k] : p.w[(size_t)k * C + n];
+        const float b = MODE == 0 ? p.w[(size_t)n * C + k + 1] : p.w[(size_t)(k + 1) * C + n];
+        *reinterpret_cast<unsigned *>(wt + n * PITCH + k) = pack_bf16(a, b);
+    }
+    if (tid < C) sbias[tid] = (MODE == 0 && p.bias) ? p.bias[tid] : 0.f;
+    // ---- this thread's staging pieces: piece i = (row tid / CPR + (256 / CPR) i, channels cc8 .. cc8+7), the SAME channels for every piece ----
+    const int prow = tid / CPR, cc8 = (tid % CPR) * 8;
+    constexpr int RSTEP = 256 / CPR;
+    // per-channel constants of the staging transform.  FWD: k0 = fs = invstd*gamma, k1 = off = beta - mean*fs.
+    // BWD: k0 = sc = gamma*invstd, k1 = sc*invstd*dgamma/M, k2 = sc*dbeta/M - k1*mean  (dh = sc*dy - (k1*h + k2))
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cc8 + e;
+        if (MODE == 0) {
+            k0[e] = p.invstd[c] * p.gamma[c];
+            k1[e] = __builtin_fmaf(-p.mean[c], k0[e], p.beta[c]);
+            k2[e] = 0.f;
+        } else {
+            k0[e] = p.gamma[c] * p.invstd[c];
+            k1[e] = k0[e] * p.invstd[c] * (p.dgamma[c] * p.inv_m);
+            k2[e] = __builtin_fmaf(k0[e], p.dbeta[c] * p.inv_m, -(k1[e] * p.mean[c]));
+        }
+    }
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    const int64_t ntiles = (p.M + ROWS - 1) / ROWS;
+    v4f px[PIECES], pg[MODE == 1 ? PIECES : 1];
+    auto prefetch = [&](int64_t t) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int64_t m = t * ROWS + prow + RSTEP * i;
+            const size_t off = (size_t)(m < p.M ? m : p.M - 1) * C + cc8;     // clamped: always inside the tensor
+            px[i] = *reinterpret_cast<const v4f *>(p.x + off);
+            if (MODE == 1) pg[i] = *reinterpret_cast<const v4f *>(p.g + off);
+        }
+    };
+    auto stage = [&](int64_t t) {       // registers -> transform -> LDS tile (and, backward, dh -> global)
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = prow + RSTEP * i;
+            const int64_t m = t * ROWS + row;
+            float xv[8], o[8];
+            Elem<bf16_t>::unpack16(px[i], xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaxf(__builtin_fmaf(xv[e], k0[e], k1[e]), 0.f);
+            } else {
+                float gv[8];
+                Elem<bf16_t>::unpack16(pg[i], gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(k0[e], gv[e], -__builtin_fmaf(k1[e], xv[e], k2[e]));
+            }
+            const v4u pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+            *reinterpret_cast<v4u *>(tile + row * PITCH + cc8) = pk;
+            if (MODE == 1 && m < p.M) {
+                *reinterpret_cast<v4u *>(p.mid + (size_t)m * C + cc8) = pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[e] += o[e];
+            }
+        }
+    };
+
+    if ((int64_t)blockIdx.x < ntiles) { prefetch(blockIdx.x); stage(blockIdx.x); }
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t nxt = t + gridDim.x;
+        if (nxt < ntiles) prefetch(nxt);
+        v16f acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        const bf16_t *brow = tile + (32 * wave + l31) * PITCH + 8 * hb;
+        const bf16_t *arow = wt + l31 * PITCH + 8 * hb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f *>(brow + 16 * ks));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f *>(arow + 32 * nb * PITCH + 16 * ks));
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+            }
+        }
+        // result of this wave's 32 rows back over its own rows of the tile (no other wave reads them): lane = row,
+        // registers 4q .. 4q+3 of block nb = channels 32 nb + 8 q + 4 hb .. +3
+        bf16_t *orow = tile + (32 * wave + l31) * PITCH;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * nb + 8 * q + 4 * hb;
+                const v4f bv = *reinterpret_cast<const v4f *>(sbias + ch);
+                const v2u pk = {pack_bf16(acc[nb][4 * q] + bv.x, acc[nb][4 * q + 1] + bv.y), pack_bf16(acc[nb][4 * q + 2] + bv.z, acc[nb][4 * q + 3] + bv.w)};
+                *reinterpret_cast<v2u *>(orow + ch) = pk;
+            }
+        __syncthreads();                       // the output tile is complete
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = prow + RSTEP * i;
+            const int64_t m = t * ROWS + row;
+            if (m < p.M) *reinterpret_cast<v4f *>(p.out + (size_t)m * C + cc8) = *reinterpret_cast<const v4f *>(tile + row * PITCH + cc8);
+        }
+        __syncthreads();                       // ... and has left LDS
+        if (nxt < ntiles) stage(nxt);
+        __syncthreads();
+    }
+    if (MODE == 1 && p.colsum_partial) {
+        // column sums of dh over this block's tiles: threads with the same channel group (tid % CPR) are combined in row-slot order
+        float *red = reinterpret_cast<float *>(tile);      // the tile is free now (the loop ended on a barrier)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = csum[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            const int grp = c >> 3, e = c & 7;
+            float s = 0.f;
+            for (int r = 0; r < RSTEP; ++r) s += red[(r * CPR + grp) * 8 + e];
+            p.colsum_partial[(size_t)blockIdx.x * C + c] = s;
+        }
+    }
+}
+
+template <int NB, int MODE>
+int launch_flat(const FlatParams &p, int blocks, hipStream_t s)
+{
+    constexpr int C = 32 * NB;
+    const size_t lds = (size_t)(ROWS + C) * (C + 8) * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536 - 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_gemm_kernel<NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return nsg_fail((int)e, "flat_gemm: cannot reserve %zu bytes of LDS", lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((flat_gemm_kernel<NB, MODE>), dim3(blocks), dim3(256), lds, s, p);
+    return nsg_check_launch("flat_gemm_kernel");
+}
+
+template <int MODE>
+int dispatch_flat(const FlatParams &p, int C, int blocks, hipStream_t s)
+{
+    switch (C / 32) {
+    case 1: return launch_flat<1, MODE>(p, blocks, s);
+    case 2: return launch_flat<2, MODE>(p, blocks, s);
+    default: return launch_flat<4, MODE>(p, blocks, s);
+    }
+}
+
+constexpr int FLAT_BLOCKS = 1024;
+
+}  // namespace
+
+// (the staging keeps a thread on one channel group: 256 threads must be a whole number of tile rows, i.e. C / 8 divides 256)
+bool nsg_flat1x1_supported(int dtype, int C) { return dtype == NSG_BF16 && (C == 32 || C == 64 || C == 128); }
+
+size_t nsg_flat1x1_workspace_bytes(int C) { return nsg_align_up((size_t)FLAT_BLOCKS * C * sizeof(float), 256); }
+
+// y = relu((x - mean) * invstd * gamma + beta) * W^T + bias
+int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
+                               const float *bias, void *y, int64_t M, int C, void *ws, hipStream_t s)
+{
+    FlatParams p = {};
+    p.x = reinterpret_cast<const bf16_t *>(x); p.w = w; p.bias = bias; p.out = reinterpret_cast<bf16_t *>(y); p.M = M;
+    p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+    const int64_t nt = (M + ROWS - 1) / ROWS;
+    return dispatch_flat<0>(p, C, (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS), s);
+}
+
+// dh = BatchNorm backward of dy at input h (no ReLU), stored; dx = dh * W; partial column sums of dh -> colsum_partial [blocks][C];
+// returns the number of blocks through *nblocks
+int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
+                                const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks, hipStream_t s)
+{
+    float *partial = reinterpret_cast<float *>(ws);
+    FlatParams p = {};
+    p.x = reinterpret_cast<const bf16_t *>(h); p.g = reinterpret_cast<const bf16_t *>(dy); p.w = w;
+    p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.dgamma = dgamma; p.dbeta = dbeta; p.inv_m = 1.f / (float)M;
+    p.out = reinterpret_cast<bf16_t *>(dx); p.mid = reinterpret_cast<bf16_t *>(dh); p.colsum_partial = partial; p.M = M;
+    const int64_t nt = (M + ROWS - 1) / ROWS;
+    const int blocks = (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS);
+    *nblocks = blocks;
+    return dispatch_flat<1>(p, C, blocks, s);
+}

@@ -293,7 +293,7 @@ __device__ __forceinline__ s16x4 lds_tr_read(const bf16_t *p)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
 }
 
-template <int WM, int WN, int TM, int TN, bool RELU>
+template <int WM, int WN, int TM, int TN, bool RELU, bool AFFQ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_gemm_bf16(const WgradParams p)
 {
     constexpr int TA = WM * TM * 32;
@@ -377,6 +377,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const s16x8 f8 = {fl, fl, fl, fl, fl, fl, fl, fl};
         return __builtin_bit_cast(v4f, __builtin_elementwise_max(sv, f8));
     };
+    // AFFQ: this thread's 8 channels of Q (the same for every piece) go through max(fma(q, fs, off), 0): the BatchNorm + ReLU
+    // that produced the conv's input, applied here instead of in a pass of its own (1x1 conv: no padding, and rows past
+    // the slab multiply zero rows of P)
+    float qfs[8], qoff[8];
+    if (AFFQ) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + qc8 + e;
+            qfs[e] = c < p.C ? p.q_invstd[c] * p.q_gamma[c] : 0.f;
+            qoff[e] = c < p.C ? __builtin_fmaf(-p.q_mean[c], qfs[e], p.q_beta[c]) : 0.f;
+        }
+    }
+    auto affq = [&](v4f v) {
+        float x[8];
+        Elem<bf16_t>::unpack16(v, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(__builtin_fmaf(x[e], qfs[e], qoff[e]), 0.f);
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const f2_t f = {x[2 * i], x[2 * i + 1]}; u[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t)); }
+        return v4f{nsg_bitsf(u[0]), nsg_bitsf(u[1]), nsg_bitsf(u[2]), nsg_bitsf(u[3])};
+    };
     auto lstore = [&](int buf, const v4f (&rp)[PJ], const v4f (&rq)[QJ]) {
         bf16_t *ps = Ps + buf * KPB * PP;
         bf16_t *qs = Qs + buf * KPB * QP;
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             *reinterpret_cast<v4f *>(ps + (ppix + PSTEP * j) * PP + pa8) = RELU ? floor8(rp[j], pfl) : rp[j];
 #pragma unroll
         for (int j = 0; j < QJ; ++j)
-            *reinterpret_cast<v4f *>(qs + (qpix + QSTEP * j) * QP + qc8) = RELU ? floor8(rq[j], qfl) : rq[j];
+            *reinterpret_cast<v4f *>(qs + (qpix + QSTEP * j) * QP + qc8) = AFFQ ? affq(rq[j]) : (RELU ? floor8(rq[j], qfl) : rq[j]);
     };
 
     v16f acc[TM][TN];
@@ -731,13 +755,18 @@ int launch_wg_bf16(const WgradParams &p, int nslab, hipStream_t s)
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
         for (const void *f : {reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false>),
-                              reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, true>)}) {
+                              reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, true>),
+                              reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false, true>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
         }
         attr_set = true;
     }
-    if (p.relu_p || p.relu_q) hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN, true>), grid, dim3(256), lds, s, p);
+    if (p.q_mean) {
+        if (p.relu_p || p.relu_q || p.KH * p.KW != 1 || p.pad || p.pad_w || p.stride != 1)
+            return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: the BatchNorm-on-load operand is for plain 1x1 convolutions");
+        hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN, false, true>), grid, dim3(256), lds, s, p);
+    } else if (p.relu_p || p.relu_q) hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN, true>), grid, dim3(256), lds, s, p);
     else                      hipLaunchKernelGGL((wgrad_gemm_bf16<WM, WN, TM, TN, false>), grid, dim3(256), lds, s, p);
     return nsg_check_launch("wgrad_gemm_bf16");
 }

@@ -186,6 +186,8 @@ struct WgradParams {
     int Mp;         // B*PH*PW
     int slab_rows;  // multiple of 32
     int relu_p, relu_q, onehot;
+    // bf16 1x1 only, or null: Q is used as max(fma(Q, fs, off), 0), fs = invstd*gamma, off = beta - mean*fs (BatchNorm + ReLU on the operand's way in)
+    const float *q_mean, *q_invstd, *q_gamma, *q_beta;
     FastDiv div_pw, div_phw;   // filled in by nsg_launch_wgrad
     unsigned p_bytes, q_bytes; // sizes of P and Q in bytes (filled in by nsg_launch_wgrad; buffer-load range checks)
     unsigned long long *stamps;  // diagnostics only
@@ -202,3 +204,5 @@ int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, fl
                             float *invstd, float *running_mean, float *running_var, hipStream_t s);
 // dbeta[c] = sum_s partial[s][0][c], dgamma[c] = sum_s partial[s][1][c] over nslab <= 1024 slabs of [2][C] (fixed order, double)
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s);
+// out[c] = sum_s partial[s][c] over nslab <= 1024 slabs of [C] (fixed order, double)
+int nsg_launch_slab_sum_final(const float *partial, int nslab, int C, float *out, hipStream_t s);

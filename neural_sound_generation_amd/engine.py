@@ -76,6 +76,10 @@ FUSED_C1_LAYER = _os.environ.get("NSG_FUSED_C1_LAYER", "1") == "1"
 # tensor nor the transposed conv's data gradient (ops.bn_relu_c1convt_*; bf16 tensors, D = 32..128).  NSG_FUSED_OUT_LAYER=0
 # restores the separate operators.
 FUSED_OUT_LAYER = _os.environ.get("NSG_FUSED_OUT_LAYER", "1") == "1"
+# The ResBlock's 1x1 conv as a flat GEMM with the BatchNorm arithmetic of its neighbours in the operand staging
+# (ops.bn_relu_conv1x1_* / ops.bn_backward_conv1x1_dgrad; bf16 tensors, dim = 32, 64, 128): relu(bn1(h1)) is never stored
+# and bn2's input gradient is produced and consumed in one pass.  NSG_FUSED_1X1=0 restores the separate operators.
+FUSED_1X1 = _os.environ.get("NSG_FUSED_1X1", "1") == "1"
 
 
 # num_batches_tracked += 1 per BatchNorm is ten tiny launches a step; a fused step collects the counters here
@@ -146,8 +150,13 @@ def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_
     d2 = ops.conv_desc(B, H, W, D, D, 1, 1, 0, dtype=r.dtype)
     (wf1, wd1), (wf2, wd2) = packs if packs is not None else (ops.pack_weights(d1, P.conv1.weight), ops.pack_weights(d2, P.conv2.weight))
     h1, m1, i1 = _conv_bn(d1, r, wf1, P.conv1, P.bn1, training)
-    a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
-    h2, m2, i2 = _conv_bn(d2, a1, wf2, P.conv2, P.bn2, training)
+    if FUSED_1X1 and ops.bn_relu_conv1x1_supported(r.dtype, D):
+        a1 = None                                    # relu(bn1(h1)) is built inside the GEMM's operand staging, here and in the backward
+        h2 = ops.bn_relu_conv1x1_forward(h1, m1, i1, P.bn1.weight, P.bn1.bias, P.conv2.weight, P.conv2.bias)
+        m2, i2 = _bn_forward(h2, P.bn2, training)
+    else:
+        a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
+        h2, m2, i2 = _conv_bn(d2, a1, wf2, P.conv2, P.bn2, training)
     y = ops.bn_apply(h2, m2, i2, P.bn2.weight, P.bn2.bias, relu=False, residual=r, relu_residual=False, out_dtype=out_dtype,
                      relu_out=relu_out)
     saved = (r, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2)
@@ -164,9 +173,14 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     # BatchNorm's input gradient, emitted by the BN-backward kernel itself (dx_colsum)
     dbias2 = o[5] if o[5] is not None else torch.empty(D, dtype=torch.float32, device=h2.device)
     dbias1 = o[1] if o[1] is not None else torch.empty(D, dtype=torch.float32, device=h2.device)
-    dh2, dg2, db2n = ops.bn_backward(h2, None, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7], dx_colsum=dbias2)
-    dw2, _ = ops.conv_wgrad(d2, a1, dh2, P.conv2.weight.shape, dw=o[4], want_bias=False)
-    da1 = ops.conv_dgrad(d2, dh2, wd2)
+    if a1 is None:      # flat-GEMM 1x1: bn2's sums, then its apply + the conv's data gradient in one pass, the weight gradient from h1
+        dg2, db2n = ops.bn_backward_sums(h2, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7])
+        dh2, da1 = ops.bn_backward_conv1x1_dgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight, dh_colsum=dbias2)
+        dw2 = ops.bn_relu_conv1x1_wgrad(h1, m1, i1, P.bn1.weight, P.bn1.bias, dh2, dw=o[4])
+    else:
+        dh2, dg2, db2n = ops.bn_backward(h2, None, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7], dx_colsum=dbias2)
+        dw2, _ = ops.conv_wgrad(d2, a1, dh2, P.conv2.weight.shape, dw=o[4], want_bias=False)
+        da1 = ops.conv_dgrad(d2, dh2, wd2)
     dh1, dg1, db1n = ops.bn_backward(h1, None, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3], dx_colsum=dbias1,
                                      relu_beta=P.bn1.bias)   # ReLU mask re-derived from h1: a1 is not read
     dw1, _ = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, dw=o[0], want_bias=False)   # x is the stored relu(x)

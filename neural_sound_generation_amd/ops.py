@@ -428,6 +428,69 @@ def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None
 
 
 # ------------------------------------------------------------------------------------------------
+# the ResBlock's 1x1 conv with the BatchNorm work around it folded in   (src/models.py:151-155)
+# ------------------------------------------------------------------------------------------------
+def bn_relu_conv1x1_supported(dtype, C) -> bool:
+    return bool(_lib.query("nsg_bn_relu_conv1x1_supported", c_int32(nsg_dtype(dtype)), c_int32(C)))
+
+
+def _ws_1x1(M, C, dev):
+    nb = _lib.query("nsg_bn_relu_conv1x1_workspace_bytes", c_int64(M), c_int32(C))
+    return WS.get(nb, dev), nb
+
+
+def bn_relu_conv1x1_forward(x, mean, invstd, gamma, beta, w, bias):
+    """y = relu(bn(x)) * w^T + bias on NHWC rows; relu(bn(x)) is never stored.  w (C, C, 1, 1) fp32."""
+    _chk(x, "x", None); _chk(w, "w", torch.float32)
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    ws, nb = _ws_1x1(M, C, x.device)
+    _lib.call("nsg_bn_relu_conv1x1_forward", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), c_int64(M), c_int32(C),
+              c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
+    return y
+
+
+def bn_relu_conv1x1_wgrad(x, mean, invstd, gamma, beta, dy, dw=None):
+    """dw (C, C, 1, 1) = dy^T relu(bn(x)) with the activation rebuilt from x on the operand's way into the MFMA."""
+    _chk(x, "x", None); _chk(dy, "dy", x.dtype)
+    C = x.shape[-1]
+    M = x.numel() // C
+    dw = dw if dw is not None else torch.empty((C, C, 1, 1), dtype=torch.float32, device=x.device)
+    ws, nb = _ws_1x1(M, C, x.device)
+    _lib.call("nsg_bn_relu_conv1x1_wgrad", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dw), c_int64(M), c_int32(C),
+              c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
+    return dw
+
+
+def bn_backward_sums(x, dy, mean, invstd, gamma, dgamma=None, dbeta=None, relu_beta=None):
+    """The reduction half of bn_backward: (dgamma, dbeta)."""
+    _chk(x, "x", None); _chk(dy, "dy", x.dtype)
+    C = mean.numel()
+    M = x.numel() // C
+    dgamma = dgamma if dgamma is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
+    ws = WS.get(nb, x.device)
+    _lib.call("nsg_bn_backward_sums", _p(x), _p(None), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(relu_beta), _p(dgamma), _p(dbeta),
+              c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
+    return dgamma, dbeta
+
+
+def bn_backward_conv1x1_dgrad(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh_colsum=None):
+    """(dh, dx): dh = the BatchNorm's input gradient (no ReLU) at input h, dx = dh * w (the data gradient of the 1x1 conv that
+    wrote h); dh_colsum: optional [C] tensor receiving dh's column sums (that conv's bias gradient)."""
+    _chk(h, "h", None); _chk(dy, "dy", h.dtype); _chk(w, "w", torch.float32)
+    C = h.shape[-1]
+    M = h.numel() // C
+    dh, dx = torch.empty_like(h), torch.empty_like(h)
+    ws, nb = _ws_1x1(M, C, h.device)
+    _lib.call("nsg_bn_backward_conv1x1_dgrad", _p(h), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(w), _p(dh), _p(dx),
+              _p(dh_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(h.dtype)), _p(ws), c_size_t(nb), _stream())
+    return dh, dx
+
+
+# ------------------------------------------------------------------------------------------------
 # decoder.4-7 as one operator: BatchNorm2d -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) [-> Tanh]   (src/models.py:180-183)
 # ------------------------------------------------------------------------------------------------
 def bn_relu_c1convt_supported(dtype, C) -> bool:

@@ -591,6 +591,51 @@ def test_bn_relu_c1convt_fused_output_layer(B, H, W, C):
     _close(dw.cpu(), dw2.cpu(), tol=2e-3, what="dw vs separate operators")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 10, 12, 32), (3, 20, 64, 128), (1, 7, 37, 64), (2, 5, 130, 64), (4, 20, 256, 128)])
+def test_resblock_1x1_conv_with_batchnorm_in_the_operand_staging(B, H, W, C):
+    """nsg_bn_relu_conv1x1_* / nsg_bn_backward_conv1x1_dgrad / nsg_bn_backward_sums (bf16): against the separate operators of
+    this library on the same tensors (which store the intermediate tensors as bf16 too: differences are single bf16
+    roundings of O(1) values accumulated over C products -> 4e-3 of the largest value) and against CPU PyTorch."""
+    g = torch.Generator().manual_seed(C + W)
+    M = B * H * W
+    x = gpu(torch.randn(B, H, W, C, generator=g) * 1.3 + 0.4).bfloat16()
+    w = gpu(torch.randn(C, C, 1, 1, generator=g) * 0.15)
+    b = gpu(torch.randn(C, generator=g) * 0.1)
+    gamma, beta = gpu(torch.rand(C, generator=g) + 0.5), gpu(torch.randn(C, generator=g) * 0.3)
+    assert ops.bn_relu_conv1x1_supported(torch.bfloat16, C) and not ops.bn_relu_conv1x1_supported(torch.bfloat16, 96)
+    mean, invstd = ops.bn_stats(x, C, None, None)
+    d = ops.conv_desc(B, H, W, C, C, 1, 1, 0, dtype=torch.bfloat16)
+    wf, wd = ops.pack_weights(d, w)
+    a = ops.bn_apply(x, mean, invstd, gamma, beta, relu=True)
+    y_ref = ops.conv_forward(d, a, wf, b)
+    y = ops.bn_relu_conv1x1_forward(x, mean, invstd, gamma, beta, w, b)
+    _close(y.float().cpu(), y_ref.float().cpu(), tol=8e-3, what="fused 1x1 forward vs separate operators")
+    # CPU fp32 reference of the same math on the bf16-rounded input
+    xa = torch.relu((x.float().cpu() - mean.cpu()) * (invstd.cpu() * gamma.cpu()) + beta.cpu())
+    y_cpu = xa.reshape(M, C) @ w.cpu().reshape(C, C).t() + b.cpu()
+    _close(y.float().cpu().reshape(M, C), y_cpu, tol=1e-2, what="fused 1x1 forward vs fp32")
+
+    dy = gpu(torch.randn(B, H, W, C, generator=g)).bfloat16()
+    dw_ref, _ = ops.conv_wgrad(d, a, dy, (C, C, 1, 1), want_bias=False)
+    dw = ops.bn_relu_conv1x1_wgrad(x, mean, invstd, gamma, beta, dy)
+    _close(dw.cpu(), dw_ref.cpu(), tol=2e-3, what="fused 1x1 wgrad vs separate operators")
+
+    # the second BatchNorm's backward + the 1x1 conv's data gradient
+    h = y_ref
+    m2, i2 = ops.bn_stats(h, C, None, None)
+    g2 = gpu(torch.rand(C, generator=g) + 0.5)
+    cs_ref = torch.empty(C, device=DEV)
+    dh_ref, dg_ref, db_ref = ops.bn_backward(h, None, dy, m2, i2, g2, dx_colsum=cs_ref)
+    dx_ref = ops.conv_dgrad(d, dh_ref, wd)
+    dg, db = ops.bn_backward_sums(h, dy, m2, i2, g2)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    cs = torch.empty(C, device=DEV)
+    dh, dx = ops.bn_backward_conv1x1_dgrad(h, dy, m2, i2, g2, dg, db, w, dh_colsum=cs)
+    _close(dh.float().cpu(), dh_ref.float().cpu(), tol=8e-3, what="fused dh vs bn_backward")
+    _close(dx.float().cpu(), dx_ref.float().cpu(), tol=1e-2, what="fused dx vs separate operators")
+    assert float((cs - cs_ref).abs().max()) <= 2e-3 * float(dh_ref.float().abs().sum(dim=(0, 1, 2)).max()) + 1e-5
+
+
 def test_batchnorm_eval():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 16, 6, 5, generator=g)
