@@ -310,6 +310,13 @@ NSG_API size_t nsg_bn_relu_conv1x1_workspace_bytes(int64_t M, int32_t C);
 NSG_API int nsg_bn_relu_conv1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
                                         const float *w, const float *bias, void *y, int64_t M, int32_t C, int32_t dtype,
                                         void *workspace, size_t workspace_bytes, void *stream);
+/* The same, plus the batch statistics of y taken from the store phase (what nsg_bn_stats(y) computes, for the BatchNorm
+ * that follows): mean_y / invstd_y [C] out, running statistics updated with `momentum` when not NULL. */
+NSG_API int nsg_bn_relu_conv1x1_forward_bnstats(const void *x, const float *mean, const float *invstd, const float *gamma,
+                                                const float *beta, const float *w, const float *bias, void *y, float eps,
+                                                float momentum, float *mean_y, float *invstd_y, float *running_mean_y,
+                                                float *running_var_y, int64_t M, int32_t C, int32_t dtype, void *workspace,
+                                                size_t workspace_bytes, void *stream);
 /* dw[o][i] = sum_m dy[m][o] * relu(bn(x))[m][i]                        (nsg_conv_wgrad with the activation rebuilt from x) */
 NSG_API int nsg_bn_relu_conv1x1_wgrad(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
                                       const void *dy, float *dw, int64_t M, int32_t C, int32_t dtype, void *workspace,

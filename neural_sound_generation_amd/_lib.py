@@ -75,6 +75,8 @@ _SIGS = {
     "nsg_bn_relu_conv1x1_supported": (c_int32, [c_int32, c_int32]),
     "nsg_bn_relu_conv1x1_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "nsg_bn_relu_conv1x1_forward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
+    "nsg_bn_relu_conv1x1_forward_bnstats": (None, [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P,
+                                                   c_size_t, _P]),
     "nsg_bn_relu_conv1x1_wgrad": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_bn_backward_conv1x1_dgrad": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_bn_backward_sums": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),

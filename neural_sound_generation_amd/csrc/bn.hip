@@ -145,33 +145,53 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__rest
     }
 }
 
-// tiles: [ntiles][3][C] = (count n_t, sum S_t, M2_t about the tile mean), written by the conv epilogue.
+// tiles: [ntiles][3][C] = (count n_t, sum S_t, M2_t about the tile mean), written by a producer's epilogue / statistics pass.
 // With N = sum n_t, S = sum S_t:  mean = S/N,  M2 = sum_t ( M2_t + S_t^2/n_t ) - S^2/N  (double).
-__global__ __launch_bounds__(256) void bn_stats_tiles_final_kernel(const float *__restrict__ tiles, int ntiles, int64_t M, int C,
-                                                                   float eps, float momentum, float *mean, float *invstd,
-                                                                   float *running_mean, float *running_var)
+// Two stages, both with a thread per channel (coalesced rows of the tile records): TILE_CHUNKS blocks each fold a
+// contiguous run of tiles in tile order into (N, S, Q) per channel, then one block folds the chunks in chunk order.
+constexpr int TILE_CHUNKS = 64;
+__global__ __launch_bounds__(256) void bn_stats_tiles_fold_kernel(const float *__restrict__ tiles, int ntiles, int C, double *__restrict__ chunks)
 {
-    __shared__ double sN[256], sS[256], sQ[256];
+    __shared__ double red[3][256];
     const int tid = threadIdx.x;
-    const int j = tid & 31;
-    const int c = blockIdx.x * 8 + (tid >> 5);
-    double N = 0.0, S = 0.0, Q = 0.0;
-    if (c < C) {
-        for (int t = j; t < ntiles; t += 32) {
-            const double n = tiles[(size_t)t * 3 * C + c];
-            if (n == 0.0) continue;
-            const double st = tiles[(size_t)t * 3 * C + C + c];
-            const double qt = tiles[(size_t)t * 3 * C + 2 * C + c];
-            N += n;
-            S += st;
-            Q += qt + st * st / n;
+    const int cx = tid & 63, ty = tid >> 6;
+    const int per = (ntiles + TILE_CHUNKS - 1) / TILE_CHUNKS;
+    const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
+    for (int cb = 0; cb < C; cb += 64) {
+        const int c = cb + cx;
+        double N = 0.0, S = 0.0, Q = 0.0;
+        if (c < C)
+            for (int t = t0 + ty; t < t1; t += 4) {
+                const float *rec = tiles + (size_t)t * 3 * C + c;
+                const double n = rec[0];
+                if (n == 0.0) continue;
+                const double st = rec[C], qt = rec[2 * C];
+                N += n;
+                S += st;
+                Q += qt + st * st / n;
+            }
+        red[0][tid] = N; red[1][tid] = S; red[2][tid] = Q;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            double *dst = chunks + (size_t)blockIdx.x * 3 * C;
+            dst[c] = ((red[0][cx] + red[0][64 + cx]) + red[0][128 + cx]) + red[0][192 + cx];
+            dst[C + c] = ((red[1][cx] + red[1][64 + cx]) + red[1][128 + cx]) + red[1][192 + cx];
+            dst[2 * C + c] = ((red[2][cx] + red[2][64 + cx]) + red[2][128 + cx]) + red[2][192 + cx];
         }
+        __syncthreads();
     }
-    sN[tid] = N; sS[tid] = S; sQ[tid] = Q;
-    __syncthreads();
-    if (j != 0 || c >= C) return;
-    N = 0.0; S = 0.0; Q = 0.0;
-    for (int k = 0; k < 32; ++k) { N += sN[tid + k]; S += sS[tid + k]; Q += sQ[tid + k]; }
+}
+__global__ __launch_bounds__(256) void bn_stats_tiles_final_kernel(const double *__restrict__ chunks, int64_t M, int C, float eps, float momentum,
+                                                                   float *mean, float *invstd, float *running_mean, float *running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double N = 0.0, S = 0.0, Q = 0.0;
+    for (int k = 0; k < TILE_CHUNKS; ++k) {
+        N += chunks[(size_t)k * 3 * C + c];
+        S += chunks[(size_t)k * 3 * C + C + c];
+        Q += chunks[(size_t)k * 3 * C + 2 * C + c];
+    }
     const double mu = S / N;
     double m2 = Q - S * S / N;
     if (m2 < 0.0) m2 = 0.0;
@@ -430,9 +450,18 @@ inline int check_mc(const char *fn, int64_t M, int C, int dtype)
 int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, float eps, float momentum, float *mean,
                             float *invstd, float *running_mean, float *running_var, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 7) / 8), dim3(256), 0, s, tiles, ntiles, M, C, eps, momentum, mean,
-                       invstd, running_mean, running_var);
+    // the chunk records live behind the tile records (callers size the tile buffer with nsg_bn_tiles_bytes)
+    double *chunks = reinterpret_cast<double *>(const_cast<float *>(tiles) + nsg_align_up((size_t)ntiles * 3 * C, 64));
+    hipLaunchKernelGGL(bn_stats_tiles_fold_kernel, dim3(TILE_CHUNKS), dim3(256), 0, s, tiles, ntiles, C, chunks);
+    hipLaunchKernelGGL(bn_stats_tiles_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, chunks, M, C, eps, momentum, mean, invstd,
+                       running_mean, running_var);
     return nsg_check_launch("bn_stats_from_tiles");
+}
+
+// bytes of a tile-statistics buffer for ntiles records of C channels: the records + the finalizer's chunk records
+size_t nsg_bn_tiles_bytes(int64_t ntiles, int C)
+{
+    return nsg_align_up((size_t)ntiles * 3 * C, 64) * sizeof(float) + (size_t)TILE_CHUNKS * 3 * C * sizeof(double) + 256;
 }
 
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s)

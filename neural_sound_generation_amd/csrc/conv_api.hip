@@ -16,7 +16,7 @@ int nsg_launch_c1_stencil_fwd(const float *img, const float *w, const float *bia
 bool nsg_flat1x1_supported(int dtype, int C);
 size_t nsg_flat1x1_workspace_bytes(int C);
 int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
-                               const float *bias, void *y, int64_t M, int C, void *ws, hipStream_t s);
+                               const float *bias, void *y, int64_t M, int C, void *ws, int want_stats, int *nblocks, hipStream_t s);
 int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
                                 const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks, hipStream_t s);
 // c1_mfma.hip / stencil_c1.hip: pieces of the fused output layer (nsg_bn_relu_c1convt_*)
@@ -278,7 +278,7 @@ inline size_t stats_tiles_bytes(const nsg_conv_desc *d)
 {
     const int64_t out_pix = (int64_t)d->B * d->OH * d->OW;
     const int64_t tiles = d->transposed ? 4 * nsg_cdiv(out_pix / 4 + d->B * (d->OH + d->OW), 128) + 8 : nsg_cdiv(out_pix, 128);
-    return nsg_align_up((size_t)(tiles + 8) * 3 * d->C_out * sizeof(float), 256);
+    return nsg_align_up(nsg_bn_tiles_bytes(tiles + 8, d->C_out), 256);
 }
 
 GatherGemmParams gg_1x1(const void *in, const void *w, const float *bias, void *out, int64_t M, int CI, int CO, int flags, int in_dtype,
@@ -462,7 +462,7 @@ int nsg_conv_forward_bnstats(const nsg_conv_desc *d, const void *x, const void *
     int ntiles = 0;
     int rc = conv_forward_impl(d, x, w_fwd, bias, y, flags, workspace, workspace_bytes, stream, tiles, &ntiles);
     if (rc) return rc;
-    NSG_REQUIRE((size_t)ntiles * 3 * d->C_out * sizeof(float) <= tb, NSG_E_WORKSPACE, "nsg_conv_forward_bnstats: tile buffer too small");
+    NSG_REQUIRE(nsg_bn_tiles_bytes(ntiles, d->C_out) <= tb, NSG_E_WORKSPACE, "nsg_conv_forward_bnstats: tile buffer too small");
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
     return nsg_bn_stats_from_tiles(tiles, ntiles, M, d->C_out, eps, momentum, mean, invstd, running_mean, running_var,
                                    (hipStream_t)stream);
@@ -667,7 +667,26 @@ int nsg_bn_relu_conv1x1_forward(const void *x, const float *mean, const float *i
     int rc = check_1x1("nsg_bn_relu_conv1x1_forward", M, C, dtype, workspace_bytes, workspace);
     if (rc) return rc;
     NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(y) && (!bias || nsg_aligned16(bias)), NSG_E_INVALID, "nsg_bn_relu_conv1x1_forward: pointers must be 16-byte aligned");
-    return nsg_launch_flat1x1_forward(x, mean, invstd, gamma, beta, w, bias, y, M, C, workspace, (hipStream_t)stream);
+    return nsg_launch_flat1x1_forward(x, mean, invstd, gamma, beta, w, bias, y, M, C, workspace, 0, nullptr, (hipStream_t)stream);
+}
+
+/* The same with the batch statistics of y (the input of the BatchNorm that follows) taken from the kernel's store phase:
+ * mean_y / invstd_y [C] out, running statistics updated (nn.BatchNorm2d training semantics), as nsg_bn_stats(y) would. */
+int nsg_bn_relu_conv1x1_forward_bnstats(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                        const float *w, const float *bias, void *y, float eps, float momentum, float *mean_y,
+                                        float *invstd_y, float *running_mean_y, float *running_var_y, int64_t M, int32_t C, int32_t dtype,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(x && mean && invstd && gamma && beta && w && y && mean_y && invstd_y, NSG_E_INVALID, "nsg_bn_relu_conv1x1_forward_bnstats: null pointer");
+    int rc = check_1x1("nsg_bn_relu_conv1x1_forward_bnstats", M, C, dtype, workspace_bytes, workspace);
+    if (rc) return rc;
+    NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(y) && (!bias || nsg_aligned16(bias)), NSG_E_INVALID,
+                "nsg_bn_relu_conv1x1_forward_bnstats: pointers must be 16-byte aligned");
+    int nblocks = 0;
+    rc = nsg_launch_flat1x1_forward(x, mean, invstd, gamma, beta, w, bias, y, M, C, workspace, 1, &nblocks, (hipStream_t)stream);
+    if (rc) return rc;
+    return nsg_bn_stats_from_tiles(reinterpret_cast<const float *>(workspace), nblocks, M, C, eps, momentum, mean_y, invstd_y, running_mean_y,
+                                   running_var_y, (hipStream_t)stream);
 }
 
 int nsg_bn_relu_conv1x1_wgrad(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const void *dy,

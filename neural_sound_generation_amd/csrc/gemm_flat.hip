@@ -40,6 +40,8 @@ struct FlatParams {
     bf16_t *out;            // FWD: y;  BWD: dx
     bf16_t *mid;            // BWD: dh
     float *colsum_partial;  // BWD: [gridDim.x][C] column sums of dh over the block's tiles (or null)
+    float *stat_tiles;      // FWD: [gridDim.x][3][C] (count, sum, M2 about the block mean) of the stored output y (or null):
+                            //      the batch statistics of the BatchNorm that follows, from the store phase instead of a pass over y
     int64_t M;
 };
 
@@ -83,9 +85,9 @@ __global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
             k2[e] = __builtin_fmaf(k0[e], p.dbeta[c] * p.inv_m, -(k1[e] * p.mean[c]));
         }
     }
-    float csum[8];
+    float csum[8], ssq[8], spv[8], scnt = 0.f;     // BWD: column sums of dh.  FWD: sums of (y - pivot), (y - pivot)^2, the pivot, the count
 #pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    for (int e = 0; e < 8; ++e) { csum[e] = 0.f; ssq[e] = 0.f; spv[e] = 0.f; }
     const int64_t ntiles = (p.M + ROWS - 1) / ROWS;
     v4f px[PIECES], pg[MODE == 1 ? PIECES : 1];
     auto prefetch = [&](int64_t t) {
@@ -161,11 +163,58 @@ __global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
         for (int i = 0; i < PIECES; ++i) {
             const int row = prow + RSTEP * i;
             const int64_t m = t * ROWS + row;
-            if (m < p.M) *reinterpret_cast<v4f *>(p.out + (size_t)m * C + cc8) = *reinterpret_cast<const v4f *>(tile + row * PITCH + cc8);
+            if (m < p.M) {
+                const v4f piece = *reinterpret_cast<const v4f *>(tile + row * PITCH + cc8);
+                *reinterpret_cast<v4f *>(p.out + (size_t)m * C + cc8) = piece;
+                if (MODE == 0 && p.stat_tiles) {          // one pass about a pivot (the thread's first value), of the values as stored
+                    float yv[8];
+                    Elem<bf16_t>::unpack16(piece, yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        spv[e] = scnt == 0.f ? yv[e] : spv[e];
+                        const float d = yv[e] - spv[e];
+                        csum[e] += d;
+                        ssq[e] = __builtin_fmaf(d, d, ssq[e]);
+                    }
+                    scnt += 1.f;
+                }
+            }
         }
         __syncthreads();                       // ... and has left LDS
         if (nxt < ntiles) stage(nxt);
         __syncthreads();
+    }
+    if (MODE == 0 && p.stat_tiles) {
+        // (count, mean, M2) of each thread, pooled over the 256 / CPR threads of its channel group in row-slot order (double)
+        float *red = reinterpret_cast<float *>(tile);      // [17][256]: 8 means, 8 M2s, the count
+        const float inv = scnt > 0.f ? 1.f / scnt : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[e * 256 + tid] = spv[e] + csum[e] * inv;
+            red[(8 + e) * 256 + tid] = fmaxf(ssq[e] - csum[e] * csum[e] * inv, 0.f);
+        }
+        red[16 * 256 + tid] = scnt;
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            const int grp = c >> 3, e = c & 7;
+            double N = 0.0, S = 0.0;
+            for (int r = 0; r < RSTEP; ++r) {
+                const double n = red[16 * 256 + r * CPR + grp];
+                N += n;
+                S += n * (double)red[e * 256 + r * CPR + grp];
+            }
+            const double mu = N > 0.0 ? S / N : 0.0;
+            double Q = 0.0;
+            for (int r = 0; r < RSTEP; ++r) {
+                const double n = red[16 * 256 + r * CPR + grp];
+                const double dl = (double)red[e * 256 + r * CPR + grp] - mu;
+                Q += n > 0.0 ? (double)red[(8 + e) * 256 + r * CPR + grp] + n * dl * dl : 0.0;
+            }
+            float *dst = p.stat_tiles + (size_t)blockIdx.x * 3 * C;
+            dst[c] = (float)N;
+            dst[C + c] = (float)S;
+            dst[2 * C + c] = (float)Q;
+        }
     }
     if (MODE == 1 && p.colsum_partial) {
         // column sums of dh over this block's tiles: threads with the same channel group (tid % CPR) are combined in row-slot order
@@ -186,7 +235,8 @@ template <int NB, int MODE>
 int launch_flat(const FlatParams &p, int blocks, hipStream_t s)
 {
     constexpr int C = 32 * NB;
-    const size_t lds = (size_t)(ROWS + C) * (C + 8) * sizeof(bf16_t);
+    size_t lds = (size_t)(ROWS + C) * (C + 8) * sizeof(bf16_t);
+    if (lds < 17 * 256 * sizeof(float)) lds = 17 * 256 * sizeof(float);      // the closing reductions reuse the front of it as [17][256] floats
     static bool attr_set = false;
     if (!attr_set && lds > 65536 - 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_gemm_kernel<NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -214,17 +264,25 @@ constexpr int FLAT_BLOCKS = 1024;
 // (the staging keeps a thread on one channel group: 256 threads must be a whole number of tile rows, i.e. C / 8 divides 256)
 bool nsg_flat1x1_supported(int dtype, int C) { return dtype == NSG_BF16 && (C == 32 || C == 64 || C == 128); }
 
-size_t nsg_flat1x1_workspace_bytes(int C) { return nsg_align_up((size_t)FLAT_BLOCKS * C * sizeof(float), 256); }
+size_t nsg_flat1x1_workspace_bytes(int C)
+{
+    const size_t bwd = nsg_align_up((size_t)FLAT_BLOCKS * C * sizeof(float), 256), fwd = nsg_align_up(nsg_bn_tiles_bytes(FLAT_BLOCKS, C), 256);
+    return bwd > fwd ? bwd : fwd;
+}
 
 // y = relu((x - mean) * invstd * gamma + beta) * W^T + bias
+// stat_tiles_out != null: the workspace receives one (count, sum, M2) record per block for nsg_bn_stats_from_tiles; *nblocks = their number
 int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
-                               const float *bias, void *y, int64_t M, int C, void *ws, hipStream_t s)
+                               const float *bias, void *y, int64_t M, int C, void *ws, int want_stats, int *nblocks, hipStream_t s)
 {
     FlatParams p = {};
     p.x = reinterpret_cast<const bf16_t *>(x); p.w = w; p.bias = bias; p.out = reinterpret_cast<bf16_t *>(y); p.M = M;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+    p.stat_tiles = want_stats ? reinterpret_cast<float *>(ws) : nullptr;
     const int64_t nt = (M + ROWS - 1) / ROWS;
-    return dispatch_flat<0>(p, C, (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS), s);
+    const int blocks = (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS);
+    if (nblocks) *nblocks = blocks;
+    return dispatch_flat<0>(p, C, blocks, s);
 }
 
 // dh = BatchNorm backward of dy at input h (no ReLU), stored; dx = dh * W; partial column sums of dh -> colsum_partial [blocks][C];

@@ -200,6 +200,9 @@ size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C);
 // dst[(a*C + c)*ntaps + t] = sum over slabs (fixed order) of partial; dst fully overwritten.
 int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipStream_t s);
 
+// tile-statistics records [ntiles][3][C] (count, sum, M2 about the tile mean) -> mean / invstd / running statistics.
+// The buffer must be nsg_bn_tiles_bytes(ntiles, C) long (the finalizer keeps its chunk records behind the tiles).
+size_t nsg_bn_tiles_bytes(int64_t ntiles, int C);
 int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, float eps, float momentum, float *mean,
                             float *invstd, float *running_mean, float *running_var, hipStream_t s);
 // dbeta[c] = sum_s partial[s][0][c], dgamma[c] = sum_s partial[s][1][c] over nslab <= 1024 slabs of [2][C] (fixed order, double)

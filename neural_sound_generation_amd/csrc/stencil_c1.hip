@@ -655,7 +655,7 @@ int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias
 
 namespace {
 constexpr int FUSED_BLOCKS = 1024;      // = bn.hip's MAX_SLABS (bn_bwd_final_kernel) and WGRAD_BLOCKS
-size_t fused_tiles_bytes(int C) { return nsg_align_up((size_t)2 * FUSED_BLOCKS * 3 * C * sizeof(float), 256); }
+size_t fused_tiles_bytes(int C) { return nsg_align_up(nsg_bn_tiles_bytes(2 * FUSED_BLOCKS, C), 256); }
 size_t fused_sums_bytes(int C) { return nsg_align_up((size_t)FUSED_BLOCKS * 2 * C * sizeof(float), 256); }
 int check_c1bn(const char *fn, int B, int H, int W, int C)
 {

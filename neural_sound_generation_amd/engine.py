@@ -152,8 +152,13 @@ def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_
     h1, m1, i1 = _conv_bn(d1, r, wf1, P.conv1, P.bn1, training)
     if FUSED_1X1 and ops.bn_relu_conv1x1_supported(r.dtype, D):
         a1 = None                                    # relu(bn1(h1)) is built inside the GEMM's operand staging, here and in the backward
-        h2 = ops.bn_relu_conv1x1_forward(h1, m1, i1, P.bn1.weight, P.bn1.bias, P.conv2.weight, P.conv2.bias)
-        m2, i2 = _bn_forward(h2, P.bn2, training)
+        if training:    # bn2's batch statistics come out of the GEMM's store phase
+            h2, m2, i2 = ops.bn_relu_conv1x1_forward_bnstats(h1, m1, i1, P.bn1.weight, P.bn1.bias, P.conv2.weight, P.conv2.bias,
+                                                             P.bn2.running_mean, P.bn2.running_var)
+            _bump(P.bn2)
+        else:
+            h2 = ops.bn_relu_conv1x1_forward(h1, m1, i1, P.bn1.weight, P.bn1.bias, P.conv2.weight, P.conv2.bias)
+            m2, i2 = _bn_forward(h2, P.bn2, False)
     else:
         a1 = ops.bn_apply(h1, m1, i1, P.bn1.weight, P.bn1.bias, relu=True)
         h2, m2, i2 = _conv_bn(d2, a1, wf2, P.conv2, P.bn2, training)

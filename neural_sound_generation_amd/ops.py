@@ -451,6 +451,23 @@ def bn_relu_conv1x1_forward(x, mean, invstd, gamma, beta, w, bias):
     return y
 
 
+def bn_relu_conv1x1_forward_bnstats(x, mean, invstd, gamma, beta, w, bias, running_mean=None, running_var=None, eps=BN_EPS,
+                                    momentum=BN_MOMENTUM):
+    """bn_relu_conv1x1_forward plus the batch statistics of its output (for the BatchNorm that follows), taken from the kernel's
+    store phase: returns (y, mean_y, invstd_y); running statistics updated in place."""
+    _chk(x, "x", None); _chk(w, "w", torch.float32)
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    mean_y = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd_y = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws, nb = _ws_1x1(M, C, x.device)
+    _lib.call("nsg_bn_relu_conv1x1_forward_bnstats", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), c_float(eps),
+              c_float(momentum), _p(mean_y), _p(invstd_y), _p(running_mean), _p(running_var), c_int64(M), c_int32(C),
+              c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
+    return y, mean_y, invstd_y
+
+
 def bn_relu_conv1x1_wgrad(x, mean, invstd, gamma, beta, dy, dw=None):
     """dw (C, C, 1, 1) = dy^T relu(bn(x)) with the activation rebuilt from x on the operand's way into the MFMA."""
     _chk(x, "x", None); _chk(dy, "dy", x.dtype)

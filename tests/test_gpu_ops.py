@@ -609,6 +609,15 @@ def test_resblock_1x1_conv_with_batchnorm_in_the_operand_staging(B, H, W, C):
     a = ops.bn_apply(x, mean, invstd, gamma, beta, relu=True)
     y_ref = ops.conv_forward(d, a, wf, b)
     y = ops.bn_relu_conv1x1_forward(x, mean, invstd, gamma, beta, w, b)
+    rm, rv = gpu(torch.randn(C, generator=g) * 0.1), gpu(torch.rand(C, generator=g) + 0.5)
+    rm2, rv2 = rm.clone(), rv.clone()
+    y_s, my, iy = ops.bn_relu_conv1x1_forward_bnstats(x, mean, invstd, gamma, beta, w, b, rm, rv)
+    assert torch.equal(y_s, y)
+    my_ref, iy_ref = ops.bn_stats(y, C, rm2, rv2)      # statistics from the store phase = a separate pass over y (summation order aside)
+    np.testing.assert_allclose(my.cpu().numpy(), my_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(iy.cpu().numpy(), iy_ref.cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), rm2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv2.cpu().numpy(), rtol=1e-5, atol=1e-6)
     _close(y.float().cpu(), y_ref.float().cpu(), tol=8e-3, what="fused 1x1 forward vs separate operators")
     # CPU fp32 reference of the same math on the bf16-rounded input
     xa = torch.relu((x.float().cpu() - mean.cpu()) * (invstd.cpu() * gamma.cpu()) + beta.cpu())
