@@ -323,11 +323,20 @@ NSG_API int nsg_bn_relu_conv1x1_wgrad(const void *x, const float *mean, const fl
                                       size_t workspace_bytes, void *stream);
 /* The apply half of nsg_bn_backward (no ReLU; dgamma / dbeta from nsg_bn_backward_sums) fused with the data gradient of
  * the 1x1 conv in FRONT of that BatchNorm:  dh = bn-backward(dy) at input h (stored: the weight gradient needs it),
- * dx = dh * w, dh_colsum [C] or NULL = column sums of dh (the conv's bias gradient). */
+ * dx = dh * w, dh_colsum [C] or NULL = column sums of dh (the conv's bias gradient).
+ * prev_x != NULL: the conv's input was relu(bn_prev(prev_x)); the sums of THAT BatchNorm's backward over (prev_x, dx) --
+ * what nsg_bn_backward_sums(prev_x, dx, ..., relu_beta = prev_beta) computes -- are formed while dx is written:
+ * prev_dgamma / prev_dbeta [C] out (then nsg_bn_backward_apply finishes that BatchNorm without a reduction pass). */
 NSG_API int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma,
                                           const float *dgamma, const float *dbeta, const float *w, void *dh, void *dx,
-                                          float *dh_colsum, int64_t M, int32_t C, int32_t dtype, void *workspace,
-                                          size_t workspace_bytes, void *stream);
+                                          float *dh_colsum, const void *prev_x, const float *prev_mean, const float *prev_invstd,
+                                          const float *prev_gamma, const float *prev_beta, float *prev_dgamma, float *prev_dbeta,
+                                          int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* The apply half of nsg_bn_backward alone: dgamma / dbeta are inputs. */
+NSG_API int nsg_bn_backward_apply(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd,
+                                  const float *gamma, const float *relu_beta, const float *dgamma, const float *dbeta, void *dx,
+                                  float *dx_colsum, int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes,
+                                  void *stream);
 /* The reduction half of nsg_bn_backward alone (same arguments, same values): dgamma, dbeta. */
 NSG_API int nsg_bn_backward_sums(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd,
                                  const float *gamma, const float *relu_beta, float *dgamma, float *dbeta, int64_t M, int32_t C,

@@ -582,6 +582,35 @@ int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const flo
     return nsg_check_launch("bn_backward");
 }
 
+/* The apply half of nsg_bn_backward alone: dgamma / dbeta are INPUTS (nsg_bn_backward_sums, or a producer that formed the
+ * same sums while it wrote dy). */
+int nsg_bn_backward_apply(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd, const float *gamma,
+                          const float *relu_beta, const float *dgamma, const float *dbeta, void *dx, float *dx_colsum, int64_t M, int32_t C,
+                          int32_t dtype, void *workspace, size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(x && dy && mean && invstd && gamma && dx && dgamma && dbeta, NSG_E_INVALID, "nsg_bn_backward_apply: null pointer");
+    int rc = check_mc("nsg_bn_backward_apply", M, C, dtype);
+    if (rc) return rc;
+    NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(dy) && nsg_aligned16(dx) && (!y_relu || nsg_aligned16(y_relu)), NSG_E_INVALID,
+                "nsg_bn_backward_apply: pointers must be 16-byte aligned");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_bn_workspace_bytes(M, C), NSG_E_WORKSPACE, "nsg_bn_backward_apply: workspace too small");
+    const SlabGeom g = slab_geom(M);
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = reinterpret_cast<float *>(workspace);
+    const float inv_m = 1.0f / (float)M;
+    if (dtype == NSG_BF16) {
+        typedef bf16_t T;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
+                           dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
+    } else {
+        typedef float T;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
+                           dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
+    }
+    if (dx_colsum) hipLaunchKernelGGL(slab_sum_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dx_colsum);
+    return nsg_check_launch("bn_backward_apply");
+}
+
 /* The reduction half of nsg_bn_backward alone: dgamma, dbeta (what a fused consumer of the apply half needs first). */
 int nsg_bn_backward_sums(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd, const float *gamma,
                          const float *relu_beta, float *dgamma, float *dbeta, int64_t M, int32_t C, int32_t dtype, void *workspace,

@@ -18,7 +18,9 @@ size_t nsg_flat1x1_workspace_bytes(int C);
 int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
                                const float *bias, void *y, int64_t M, int C, void *ws, int want_stats, int *nblocks, hipStream_t s);
 int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
-                                const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks, hipStream_t s);
+                                const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks,
+                                const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
+                                const float *prev_beta, float **prev_partial, hipStream_t s);
 // c1_mfma.hip / stencil_c1.hip: pieces of the fused output layer (nsg_bn_relu_c1convt_*)
 bool nsg_c1m_supported(int C);
 int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
@@ -708,8 +710,10 @@ int nsg_bn_relu_conv1x1_wgrad(const void *x, const float *mean, const float *inv
 }
 
 int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma,
-                                  const float *dgamma, const float *dbeta, const float *w, void *dh, void *dx, float *dh_colsum, int64_t M,
-                                  int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream)
+                                  const float *dgamma, const float *dbeta, const float *w, void *dh, void *dx, float *dh_colsum,
+                                  const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
+                                  const float *prev_beta, float *prev_dgamma, float *prev_dbeta, int64_t M, int32_t C, int32_t dtype,
+                                  void *workspace, size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(h && dy && mean && invstd && gamma && dgamma && dbeta && w && dh && dx, NSG_E_INVALID, "nsg_bn_backward_conv1x1_dgrad: null pointer");
     int rc = check_1x1("nsg_bn_backward_conv1x1_dgrad", M, C, dtype, workspace_bytes, workspace);
@@ -717,12 +721,19 @@ int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const float *me
     NSG_REQUIRE(nsg_aligned16(h) && nsg_aligned16(dy) && nsg_aligned16(dh) && nsg_aligned16(dx), NSG_E_INVALID,
                 "nsg_bn_backward_conv1x1_dgrad: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (prev_x)
+        NSG_REQUIRE(prev_mean && prev_invstd && prev_gamma && prev_beta && prev_dgamma && prev_dbeta && nsg_aligned16(prev_x), NSG_E_INVALID,
+                    "nsg_bn_backward_conv1x1_dgrad: the BatchNorm in front needs all of its arguments (prev_x 16-byte aligned)");
     int nblocks = 0;
-    rc = nsg_launch_flat1x1_backward(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh, dx, M, C, workspace, &nblocks, s);
+    float *prev_partial = nullptr;
+    rc = nsg_launch_flat1x1_backward(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh, dx, M, C, workspace, &nblocks, prev_x, prev_mean,
+                                     prev_invstd, prev_gamma, prev_beta, &prev_partial, s);
     if (rc) return rc;
     if (dh_colsum) {
-        return nsg_launch_slab_sum_final(reinterpret_cast<const float *>(workspace), nblocks, C, dh_colsum, s);
+        rc = nsg_launch_slab_sum_final(reinterpret_cast<const float *>(workspace), nblocks, C, dh_colsum, s);
+        if (rc) return rc;
     }
+    if (prev_x) return nsg_launch_bn_bwd_final(prev_partial, nblocks, C, prev_dgamma, prev_dbeta, s);
     return NSG_OK;
 }
 

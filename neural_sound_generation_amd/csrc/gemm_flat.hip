@@ -40,6 +40,12 @@ struct FlatParams {
     bf16_t *out;            // FWD: y;  BWD: dx
     bf16_t *mid;            // BWD: dh
     float *colsum_partial;  // BWD: [gridDim.x][C] column sums of dh over the block's tiles (or null)
+    // BWD, optional: the sums of the BatchNorm + ReLU that sits in FRONT of the conv (input prev_x, output = the conv's input):
+    // prev_partial[gridDim.x][2][C] = (sum g, sum g * xhat) with g = dx where that ReLU passed -- nsg_bn_backward_sums of
+    // (prev_x, dx) formed while dx is written
+    const bf16_t *prev_x;
+    const float *prev_mean, *prev_invstd, *prev_gamma, *prev_beta;
+    float *prev_partial;
     float *stat_tiles;      // FWD: [gridDim.x][3][C] (count, sum, M2 about the block mean) of the stored output y (or null):
                             //      the batch statistics of the BatchNorm that follows, from the store phase instead of a pass over y
     int64_t M;
@@ -47,7 +53,7 @@ struct FlatParams {
 
 // MODE 0: forward (a = max(fma(x, fs, off), 0));  MODE 1: backward (dh = fma(sc, dy, -fma(k1, h, k0)); W used transposed)
 template <int NB, int MODE>     // C = 32 NB
-__global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void flat_gemm_kernel(const FlatParams p)
 {
     constexpr int C = 32 * NB, KS = C / 16, PITCH = C + 8, CPR = C / 8, PIECES = ROWS * CPR / 256;
     static_assert(256 % CPR == 0, "a thread stages the same channel group in every piece");
@@ -88,6 +94,15 @@ __global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
     float csum[8], ssq[8], spv[8], scnt = 0.f;     // BWD: column sums of dh.  FWD: sums of (y - pivot), (y - pivot)^2, the pivot, the count
 #pragma unroll
     for (int e = 0; e < 8; ++e) { csum[e] = 0.f; ssq[e] = 0.f; spv[e] = 0.f; }
+    const bool prev = MODE == 1 && p.prev_x != nullptr;
+    float pmu[8], pfs[8], pbe[8], ps1[8], ps2[8];     // the BatchNorm in front: mean, invstd*gamma, beta; its two sums
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        pmu[e] = prev ? p.prev_mean[cc8 + e] : 0.f;
+        pfs[e] = prev ? p.prev_invstd[cc8 + e] * p.prev_gamma[cc8 + e] : 0.f;
+        pbe[e] = prev ? p.prev_beta[cc8 + e] : 0.f;
+        ps1[e] = 0.f; ps2[e] = 0.f;
+    }
     const int64_t ntiles = (p.M + ROWS - 1) / ROWS;
     v4f px[PIECES], pg[MODE == 1 ? PIECES : 1];
     auto prefetch = [&](int64_t t) {
@@ -130,6 +145,14 @@ __global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t nxt = t + gridDim.x;
         if (nxt < ntiles) prefetch(nxt);
+        v4f ph[MODE == 1 ? PIECES : 1];
+        if (prev) {                            // the rows of prev_x under THIS tile: in flight across the MFMA loop, used in the store phase
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int64_t m = t * ROWS + prow + RSTEP * i;
+                ph[i] = *reinterpret_cast<const v4f *>(p.prev_x + (size_t)(m < p.M ? m : p.M - 1) * C + cc8);
+            }
+        }
         v16f acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -166,6 +189,18 @@ __global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
             if (m < p.M) {
                 const v4f piece = *reinterpret_cast<const v4f *>(tile + row * PITCH + cc8);
                 *reinterpret_cast<v4f *>(p.out + (size_t)m * C + cc8) = piece;
+                if (prev) {                    // bn_bwd_partial_kernel's sums on (prev_x, the dx values as stored), same mask expression
+                    float dv[8], hv[8];
+                    Elem<bf16_t>::unpack16(piece, dv);
+                    Elem<bf16_t>::unpack16(ph[i], hv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float hc = hv[e] - pmu[e];
+                        const float ge = (hc * pfs[e] + pbe[e]) > 0.f ? dv[e] : 0.f;
+                        ps1[e] += ge;
+                        ps2[e] = __builtin_fmaf(ge, hc, ps2[e]);
+                    }
+                }
                 if (MODE == 0 && p.stat_tiles) {          // one pass about a pivot (the thread's first value), of the values as stored
                     float yv[8];
                     Elem<bf16_t>::unpack16(piece, yv);
@@ -215,6 +250,20 @@ __global__ __launch_bounds__(256) void flat_gemm_kernel(const FlatParams p)
             dst[C + c] = (float)S;
             dst[2 * C + c] = (float)Q;
         }
+    }
+    if (prev) {
+        float *red = reinterpret_cast<float *>(tile);      // [16][256]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[e * 256 + tid] = ps1[e]; red[(8 + e) * 256 + tid] = ps2[e]; }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            const int grp = c >> 3, e = c & 7;
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RSTEP; ++r) { a += red[e * 256 + r * CPR + grp]; b += red[(8 + e) * 256 + r * CPR + grp]; }
+            p.prev_partial[(size_t)blockIdx.x * 2 * C + c] = a;
+            p.prev_partial[(size_t)blockIdx.x * 2 * C + C + c] = b * p.prev_invstd[c];
+        }
+        __syncthreads();
     }
     if (MODE == 1 && p.colsum_partial) {
         // column sums of dh over this block's tiles: threads with the same channel group (tid % CPR) are combined in row-slot order
@@ -266,7 +315,8 @@ bool nsg_flat1x1_supported(int dtype, int C) { return dtype == NSG_BF16 && (C ==
 
 size_t nsg_flat1x1_workspace_bytes(int C)
 {
-    const size_t bwd = nsg_align_up((size_t)FLAT_BLOCKS * C * sizeof(float), 256), fwd = nsg_align_up(nsg_bn_tiles_bytes(FLAT_BLOCKS, C), 256);
+    const size_t bwd = nsg_align_up((size_t)FLAT_BLOCKS * C * sizeof(float), 256) + nsg_align_up((size_t)FLAT_BLOCKS * 2 * C * sizeof(float), 256);
+    const size_t fwd = nsg_align_up(nsg_bn_tiles_bytes(FLAT_BLOCKS, C), 256);
     return bwd > fwd ? bwd : fwd;
 }
 
@@ -287,13 +337,22 @@ int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *in
 
 // dh = BatchNorm backward of dy at input h (no ReLU), stored; dx = dh * W; partial column sums of dh -> colsum_partial [blocks][C];
 // returns the number of blocks through *nblocks
+// prev_x != null: also the partial sums of the BatchNorm + ReLU in front of the conv -> [blocks][2][C] behind the column-sum partials
 int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
-                                const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks, hipStream_t s)
+                                const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks,
+                                const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
+                                const float *prev_beta, float **prev_partial, hipStream_t s)
 {
     float *partial = reinterpret_cast<float *>(ws);
     FlatParams p = {};
     p.x = reinterpret_cast<const bf16_t *>(h); p.g = reinterpret_cast<const bf16_t *>(dy); p.w = w;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.dgamma = dgamma; p.dbeta = dbeta; p.inv_m = 1.f / (float)M;
+    if (prev_x) {
+        p.prev_x = reinterpret_cast<const bf16_t *>(prev_x);
+        p.prev_mean = prev_mean; p.prev_invstd = prev_invstd; p.prev_gamma = prev_gamma; p.prev_beta = prev_beta;
+        p.prev_partial = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + nsg_align_up((size_t)FLAT_BLOCKS * C * sizeof(float), 256));
+        if (prev_partial) *prev_partial = p.prev_partial;
+    }
     p.out = reinterpret_cast<bf16_t *>(dx); p.mid = reinterpret_cast<bf16_t *>(dh); p.colsum_partial = partial; p.M = M;
     const int64_t nt = (M + ROWS - 1) / ROWS;
     const int blocks = (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS);

@@ -180,14 +180,17 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     dbias1 = o[1] if o[1] is not None else torch.empty(D, dtype=torch.float32, device=h2.device)
     if a1 is None:      # flat-GEMM 1x1: bn2's sums, then its apply + the conv's data gradient in one pass, the weight gradient from h1
         dg2, db2n = ops.bn_backward_sums(h2, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7])
-        dh2, da1 = ops.bn_backward_conv1x1_dgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight, dh_colsum=dbias2)
+        dh2, da1, dg1, db1n = ops.bn_backward_conv1x1_dgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight, dh_colsum=dbias2,
+                                                            prev=(h1, m1, i1, P.bn1.weight, P.bn1.bias), prev_dgamma=o[2], prev_dbeta=o[3])
         dw2 = ops.bn_relu_conv1x1_wgrad(h1, m1, i1, P.bn1.weight, P.bn1.bias, dh2, dw=o[4])
+        dh1 = ops.bn_backward_apply(h1, da1, m1, i1, P.bn1.weight, dg1, db1n, relu_beta=P.bn1.bias, dx_colsum=dbias1)   # bn1's sums came with da1
     else:
         dh2, dg2, db2n = ops.bn_backward(h2, None, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7], dx_colsum=dbias2)
         dw2, _ = ops.conv_wgrad(d2, a1, dh2, P.conv2.weight.shape, dw=o[4], want_bias=False)
         da1 = ops.conv_dgrad(d2, dh2, wd2)
-    dh1, dg1, db1n = ops.bn_backward(h1, None, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3], dx_colsum=dbias1,
-                                     relu_beta=P.bn1.bias)   # ReLU mask re-derived from h1: a1 is not read
+    if a1 is not None:
+        dh1, dg1, db1n = ops.bn_backward(h1, None, da1, m1, i1, P.bn1.weight, dgamma=o[2], dbeta=o[3], dx_colsum=dbias1,
+                                         relu_beta=P.bn1.bias)   # ReLU mask re-derived from h1: a1 is not read
     dw1, _ = ops.conv_wgrad(d1, x, dh1, P.conv1.weight.shape, dw=o[0], want_bias=False)   # x is the stored relu(x)
     dx = None
     if need_dx:

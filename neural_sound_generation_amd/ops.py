@@ -494,17 +494,41 @@ def bn_backward_sums(x, dy, mean, invstd, gamma, dgamma=None, dbeta=None, relu_b
     return dgamma, dbeta
 
 
-def bn_backward_conv1x1_dgrad(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh_colsum=None):
+def bn_backward_conv1x1_dgrad(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh_colsum=None, prev=None, prev_dgamma=None, prev_dbeta=None):
     """(dh, dx): dh = the BatchNorm's input gradient (no ReLU) at input h, dx = dh * w (the data gradient of the 1x1 conv that
-    wrote h); dh_colsum: optional [C] tensor receiving dh's column sums (that conv's bias gradient)."""
+    wrote h); dh_colsum: optional [C] tensor receiving dh's column sums (that conv's bias gradient).
+    prev = (prev_x, mean, invstd, gamma, beta) of the BatchNorm + ReLU in front of the conv: its backward sums over (prev_x, dx)
+    are formed while dx is written; returns (dh, dx, prev_dgamma, prev_dbeta) then."""
     _chk(h, "h", None); _chk(dy, "dy", h.dtype); _chk(w, "w", torch.float32)
     C = h.shape[-1]
     M = h.numel() // C
     dh, dx = torch.empty_like(h), torch.empty_like(h)
     ws, nb = _ws_1x1(M, C, h.device)
+    px = pm = pi = pg = pb = None
+    if prev is not None:
+        px, pm, pi, pg, pb = prev
+        _chk(px, "prev_x", h.dtype)
+        prev_dgamma = prev_dgamma if prev_dgamma is not None else torch.empty(C, dtype=torch.float32, device=h.device)
+        prev_dbeta = prev_dbeta if prev_dbeta is not None else torch.empty(C, dtype=torch.float32, device=h.device)
     _lib.call("nsg_bn_backward_conv1x1_dgrad", _p(h), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(w), _p(dh), _p(dx),
-              _p(dh_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(h.dtype)), _p(ws), c_size_t(nb), _stream())
+              _p(dh_colsum), _p(px), _p(pm), _p(pi), _p(pg), _p(pb), _p(prev_dgamma if prev is not None else None),
+              _p(prev_dbeta if prev is not None else None), c_int64(M), c_int32(C), c_int32(nsg_dtype(h.dtype)), _p(ws), c_size_t(nb), _stream())
+    if prev is not None:
+        return dh, dx, prev_dgamma, prev_dbeta
     return dh, dx
+
+
+def bn_backward_apply(x, dy, mean, invstd, gamma, dgamma, dbeta, relu_beta=None, dx_colsum=None):
+    """The apply half of bn_backward with dgamma / dbeta given: dx."""
+    _chk(x, "x", None); _chk(dy, "dy", x.dtype)
+    C = mean.numel()
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
+    ws = WS.get(nb, x.device)
+    _lib.call("nsg_bn_backward_apply", _p(x), _p(None), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(relu_beta), _p(dgamma), _p(dbeta), _p(dx),
+              _p(dx_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
+    return dx
 
 
 # ------------------------------------------------------------------------------------------------

@@ -643,6 +643,16 @@ def test_resblock_1x1_conv_with_batchnorm_in_the_operand_staging(B, H, W, C):
     _close(dh.float().cpu(), dh_ref.float().cpu(), tol=8e-3, what="fused dh vs bn_backward")
     _close(dx.float().cpu(), dx_ref.float().cpu(), tol=1e-2, what="fused dx vs separate operators")
     assert float((cs - cs_ref).abs().max()) <= 2e-3 * float(dh_ref.float().abs().sum(dim=(0, 1, 2)).max()) + 1e-5
+    # ... with the sums of the BatchNorm + ReLU in front (x, mean, invstd, gamma, beta) formed while dx is written: the same
+    # dx, and what nsg_bn_backward_sums gives on (x, that dx); then the apply half alone = bn_backward's dx
+    dh_b, dx_b, pdg, pdb = ops.bn_backward_conv1x1_dgrad(h, dy, m2, i2, g2, dg, db, w, prev=(x, mean, invstd, gamma, beta))
+    assert torch.equal(dx_b, dx) and torch.equal(dh_b, dh)
+    pdg_ref, pdb_ref = ops.bn_backward_sums(x, dx, mean, invstd, gamma, relu_beta=beta)
+    _close(pdg.cpu(), pdg_ref.cpu(), tol=1e-5, what="dgamma of the BatchNorm in front")
+    _close(pdb.cpu(), pdb_ref.cpu(), tol=1e-5, what="dbeta of the BatchNorm in front")
+    dxx_ref, _, _ = ops.bn_backward(x, None, dx, mean, invstd, gamma, relu_beta=beta)
+    dxx = ops.bn_backward_apply(x, dx, mean, invstd, gamma, pdg_ref, pdb_ref, relu_beta=beta)
+    assert torch.equal(dxx, dxx_ref)
 
 
 def test_batchnorm_eval():
