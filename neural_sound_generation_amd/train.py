@@ -14,6 +14,8 @@ Two ways to run it:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -21,6 +23,9 @@ from . import distributed as nsg_dist
 from . import engine, functional as Fn, ops
 from .optim import FlatAdam
 
+
+# The bf16 step without an fp32 z_q (see _forward_backward); NSG_LEAN_VQ=0 keeps the materialised form.
+LEAN_VQ = os.environ.get("NSG_LEAN_VQ", "1") == "1"
 
 class FusedTrainStep:
     def __init__(self, model, lr: float = 1e-3, beta: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
@@ -66,7 +71,7 @@ class FusedTrainStep:
         search = getattr(self.model.codebook, "search_impl", "mfma")
         # bf16 mode without speaker conditioning: z_q is never materialised in fp32 -- the search writes the decoder's
         # (ReLU'd, bf16) input itself, the losses read codebook[idx], the codebook gradient comes from per-code sums of z_e
-        lean = search == "bf16x3" and self.dtype == torch.bfloat16 and self.spk is None and D % 8 == 0
+        lean = LEAN_VQ and search == "bf16x3" and self.dtype == torch.bfloat16 and self.spk is None and D % 8 == 0
         if lean:
             idx, _, _, zdec = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=False, impl=search, codes_bf16="relu")
             zq = None

@@ -524,6 +524,45 @@ def test_train_from_disk_loader(tmp_path):
     assert n == len(loaders["test"]) == 1
 
 
+def test_bf16_fused_layers_equal_the_separate_operators(monkeypatch):
+    """The operators that fold BatchNorm work into a neighbouring conv (fused input layer, fused output layer, flat 1x1 GEMMs,
+    the quantiser without an fp32 z_q) against the same step on the separate operators (engine / train switches off).
+    Output layer + 1x1 + quantiser: the same bf16 tensors reach the quantiser, so the same codes (< 0.2 % differ), losses to
+    1e-4 and aligned gradients (cosine > 0.9 for every tensor that is not a noise-level conv bias in front of a BatchNorm,
+    median > 0.99).  The fused input layer does NOT round the conv output to bf16 before normalising it (it never stores
+    it), which perturbs z_e at bf16 level and moves the ~2 % of rows that sit on near-ties of the freshly initialised
+    codebook (the bf16 mode differs from fp32 by the same amount, test_bf16_mode_against_fp32_oracle): losses to 2e-3."""
+    from neural_sound_generation_amd import engine, train as T
+    c = torch.rand(4, 1, 80, 512, generator=torch.Generator().manual_seed(77)).to(DEV)
+    switches = {"FUSED_C1_LAYER": engine, "FUSED_OUT_LAYER": engine, "FUSED_1X1": engine, "LEAN_VQ": T}
+
+    def run(on):
+        for name, mod in switches.items():
+            monkeypatch.setattr(mod, name, name in on)
+        torch.manual_seed(3)
+        m = M.VQVAE(1, 128, 512, compute_dtype=torch.bfloat16).to(DEV).train()
+        st = FusedTrainStep(m, lr=1e-3)
+        l = st.forward_backward(c)
+        return [float(x) for x in l], st.last_indices.clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    ls, ids, gs = run(())
+    lf, idf, gf = run(("FUSED_OUT_LAYER", "FUSED_1X1", "LEAN_VQ"))
+    assert rel(lf[0], ls[0]) < 1e-4 and rel(lf[1], ls[1]) < 1e-4, (lf, ls)
+    assert float((idf != ids).float().mean()) < 2e-3
+    cosines = {}
+    for k in gf:
+        if is_noise_bias(k) or gs[k].norm() < 1e-7:
+            continue
+        a, b = gf[k].double().flatten(), gs[k].double().flatten()
+        cosines[k] = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    vals = sorted(cosines.values())
+    print("fused (output layer, 1x1, quantiser) vs separate operators, gradient cosines:", {k: round(v, 4) for k, v in cosines.items()})
+    assert vals[0] > 0.9 and vals[len(vals) // 2] > 0.99, cosines
+    la, ida, _ = run(tuple(switches))
+    assert rel(la[0], ls[0]) < 2e-3 and rel(la[1], ls[1]) < 2e-3, (la, ls)
+    assert float((ida != ids).float().mean()) < 0.05
+
+
 def test_bf16_mode_eval_encode_decode():
     """The inference-side surface (models.py:188-196) in the bf16 mode: same shapes / dtypes as fp32, the same codes
     except on near-ties, reconstruction within bf16 noise."""
