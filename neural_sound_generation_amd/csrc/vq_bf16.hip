@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        x2v[r] = row < N ? x2[row] : 0.f;
+        x2v[r] = (x2 && row < N) ? x2[row] : 0.f;     // x2 == null: the search runs on c2 - 2 x.e (the row constant changes no argmin)
     }
     float best[16];
     int bidx[16];
@@ -246,7 +246,11 @@ int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, 
     float *c2 = reinterpret_cast<float *>(ws + nsg_align_up((size_t)N * sizeof(float), 256));
     bf16_t *ehi = reinterpret_cast<bf16_t *>(ws + nsg_vq_workspace_bytes(N, D, K));
     bf16_t *elo = reinterpret_cast<bf16_t *>(ws + nsg_vq_workspace_bytes(N, D, K) + split_bytes(D, K));
-    int rc = nsg_rowsumsq(x, N, D, x2, stream);
+    // |x|^2 is constant along a row: it only matters for the reported distances.  Without dmin_out it is neither computed
+    // (a pass over x) nor added (the sum c2 + x2 would round the small code norms away)
+    int rc = NSG_OK;
+    if (dmin_out) rc = nsg_rowsumsq(x, N, D, x2, stream);
+    else x2 = nullptr;
     if (rc) return rc;
     rc = nsg_rowsumsq(e, K, D, c2, stream);
     if (rc) return rc;
