@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void c1m_bwd_sums_kernel(const float *__re
 // written back over the tile in LDS and stored (dx_out), and the weight gradient of the transposed conv accumulates
 // dw^T[tap][c] += patch(dpre)^T[tap][pixel] * a[pixel][c] with a = max(fma(u, fs, off), 0) rebuilt on the spot.
 template <int NW, bool SWAP>
-__global__ __launch_bounds__(64 * NW) void c1m_bwd_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ w,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void c1m_bwd_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ w,
                                                                  const float *__restrict__ bias, const bf16_t *__restrict__ dy,
                                                                  const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
