@@ -491,7 +491,8 @@ def test_batchnorm_train_forward_backward(B, C, H, W, relu, res):
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 8), (3, 80, 64, 128), (2, 20, 260, 48), (1, 6, 130, 256), (2, 4, 4, 4),
-                                     (2, 20, 260, 96), (1, 6, 130, 32), (2, 8, 12, 64), (2, 10, 300, 128)])
+                                     (2, 20, 260, 96), (1, 6, 130, 32), (2, 8, 12, 64), (2, 10, 300, 128),
+                                     (4, 80, 1024, 128)])       # the last: BASELINE configs[1]'s image extent
 @pytest.mark.parametrize("bf", [False, True], ids=["f32", "bf16"])
 def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
     """encoder.0-2 (Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU, src/models.py:165-167) as one operator whose conv output is
@@ -520,7 +521,7 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
     _close(nchw(yg.float().cpu()), y.detach(), tol=1e-2 if bf else 1e-5, what="fused layer forward")
     dyg = gpu(nhwc(dy)).to(dt)
     dw, dbias, dgm, dbt = ops.c1conv_bn_relu_backward(imgg, wg, bg, gag, beg, mean, invstd, dyg)
-    tol = 1e-2 if bf else 3e-5           # bf16: dy itself is rounded to 8 bits
+    tol = 2e-2 if bf else 3e-5           # bf16: dy, dh and the patch operand of the weight-gradient MFMA carry 8 bits (as every bf16 wgrad)
     _close(dw.cpu(), gw, tol=tol, what="fused layer dw")
     _close(dgm.cpu(), gg, tol=tol, what="fused layer dgamma")
     _close(dbt.cpu(), gbe, tol=tol, what="fused layer dbeta")
@@ -546,7 +547,8 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
         _close(dw.cpu(), dw2.cpu(), tol=2e-5, what="dw vs unfused")
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 32), (3, 40, 64, 128), (2, 10, 130, 96), (1, 3, 70, 64), (2, 5, 150, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 32), (3, 40, 64, 128), (2, 10, 130, 96), (1, 3, 70, 64), (2, 5, 150, 128),
+                                     (4, 40, 512, 128)])        # the last: BASELINE configs[1]'s decoder extent
 def test_bn_relu_c1convt_fused_output_layer(B, H, W, C):
     """decoder.4-7 (BatchNorm2d -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) -> Tanh, src/models.py:180-183) as one operator on bf16
     tensors, against CPU PyTorch autograd on the same bf16-rounded input.  The operator rounds relu(bn(u)) and the conv
@@ -576,10 +578,16 @@ def test_bn_relu_c1convt_fused_output_layer(B, H, W, C):
     # column sums of du (bias gradient of the conv in front of the BatchNorm; mathematically zero): against the fp32 values
     # before du's bf16 rounding -- bounded by the rounding of the stored du
     assert float((cs.cpu() - du.float().sum(dim=(0, 1, 2)).cpu()).abs().max()) <= 2e-2 * float(du.float().abs().sum(dim=(0, 1, 2)).max())
-    _close(nchw(du.float().cpu()), gu, tol=1e-2, what="fused output layer du")
-    _close(dw.cpu(), gw, tol=1e-2, what="fused output layer dw")
-    _close(dgm.cpu(), gg, tol=1e-2, what="fused output layer dgamma")
-    _close(dbt.cpu(), gbe, tol=1e-2, what="fused output layer dbeta")
+    # du: elements whose pre-activation sits within rounding of the ReLU threshold may take the other branch (fp32 statistics
+    # summed in another order); they are excluded from the element-wise bound and must be rare
+    t_ref = F.batch_norm(u.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5)
+    safe = t_ref.abs() > 1e-4
+    assert float((~safe).float().mean()) < 1e-3
+    _close(nchw(du.float().cpu()) * safe, gu * safe, tol=1e-2, what="fused output layer du")
+    # (the sums see the same threshold elements: each one that flips moves a sum by its whole O(1) term -> 2e-2)
+    _close(dw.cpu(), gw, tol=2e-2, what="fused output layer dw")
+    _close(dgm.cpu(), gg, tol=2e-2, what="fused output layer dgamma")
+    _close(dbt.cpu(), gbe, tol=2e-2, what="fused output layer dbeta")
     _close(dbias.cpu(), gb, tol=1e-5, what="fused output layer dbias")
     # against the separate operators of this library on the same tensors (they store a and da as bf16): same tolerance class
     d6 = ops.conv_desc(B, H, W, C, 1, 4, 2, 1, transposed=True, dtype=torch.bfloat16)
@@ -591,7 +599,8 @@ def test_bn_relu_c1convt_fused_output_layer(B, H, W, C):
     _close(dw.cpu(), dw2.cpu(), tol=2e-3, what="dw vs separate operators")
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 10, 12, 32), (3, 20, 64, 128), (1, 7, 37, 64), (2, 5, 130, 64), (4, 20, 256, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 10, 12, 32), (3, 20, 64, 128), (1, 7, 37, 64), (2, 5, 130, 64), (4, 20, 256, 128),
+                                     (33, 20, 256, 128)])       # the last: more tiles than persistent blocks (1320 > 1024)
 def test_resblock_1x1_conv_with_batchnorm_in_the_operand_staging(B, H, W, C):
     """nsg_bn_relu_conv1x1_* / nsg_bn_backward_conv1x1_dgrad / nsg_bn_backward_sums (bf16): against the separate operators of
     this library on the same tensors (which store the intermediate tensors as bf16 too: differences are single bf16
