@@ -40,7 +40,8 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "nsg_common.h"), os.path.join(ROOT, "include", "nsg.h")]
+    # every header any source may include: editing one rebuilds all objects (seconds per file)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "nsg.h")]
     cc = hipcc()
     jobs = []
     for src in SOURCES:

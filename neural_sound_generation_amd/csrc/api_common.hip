@@ -31,6 +31,21 @@ int nsg_check_launch(const char *what)
     return (int)err;
 }
 
+int nsg_lds_opt_in(LdsOptIn &once, std::initializer_list<const void *> kernels, size_t lds_bytes, const char *what)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return nsg_fail((int)e, "%s: hipGetDevice: %s", what, hipGetErrorString(e));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (once.devices.load(std::memory_order_acquire) & bit) return NSG_OK;
+    for (const void *k : kernels) {
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return nsg_fail((int)e, "%s: cannot reserve %zu bytes of LDS on device %d", what, lds_bytes, dev);
+    }
+    once.devices.fetch_or(bit, std::memory_order_release);
+    return NSG_OK;
+}
+
 extern "C" {
 
 int nsg_version(void) { return NSG_VERSION; }

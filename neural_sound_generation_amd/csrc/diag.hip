@@ -187,12 +187,8 @@ NSG_API int nsg_debug_lds_fed_loop8(int32_t blocks, int32_t chunks, int32_t mode
 {
     NSG_REQUIRE(blocks > 0 && chunks > 0 && sink, NSG_E_INVALID, "nsg_debug_lds_fed_loop8: bad argument");
     const size_t lds = (size_t)2 * 384 * 36 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_fed_loop8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "nsg_debug_lds_fed_loop8: cannot reserve LDS");
-        attr_set = true;
-    }
+    static LdsOptIn once;
+    if (const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&lds_fed_loop8_kernel)}, lds, "nsg_debug_lds_fed_loop8")) return rc;
     hipLaunchKernelGGL(lds_fed_loop8_kernel, dim3(blocks), dim3(512), lds, (hipStream_t)stream, chunks, mode, sink);
     return nsg_check_launch("lds_fed_loop8_kernel");
 }
@@ -202,12 +198,8 @@ NSG_API int nsg_debug_lds_fed_loop(int32_t blocks, int32_t chunks, int32_t mode,
 {
     NSG_REQUIRE(blocks > 0 && chunks > 0 && sink, NSG_E_INVALID, "nsg_debug_lds_fed_loop: bad argument");
     const size_t lds = (size_t)2 * 256 * 36 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_fed_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "nsg_debug_lds_fed_loop: cannot reserve LDS");
-        attr_set = true;
-    }
+    static LdsOptIn once;
+    if (const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&lds_fed_loop_kernel)}, lds, "nsg_debug_lds_fed_loop")) return rc;
     hipLaunchKernelGGL(lds_fed_loop_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, chunks, mode, sink);
     return nsg_check_launch("lds_fed_loop_kernel");
 }

@@ -286,11 +286,10 @@ int launch_flat(const FlatParams &p, int blocks, hipStream_t s)
     constexpr int C = 32 * NB;
     size_t lds = (size_t)(ROWS + C) * (C + 8) * sizeof(bf16_t);
     if (lds < 17 * 256 * sizeof(float)) lds = 17 * 256 * sizeof(float);      // the closing reductions reuse the front of it as [17][256] floats
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536 - 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_gemm_kernel<NB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "flat_gemm: cannot reserve %zu bytes of LDS", lds);
-        attr_set = true;
+    static LdsOptIn once;
+    if (lds > 65536 - 1024) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&flat_gemm_kernel<NB, MODE>)}, lds, "flat_gemm");
+        if (rc != NSG_OK) return rc;
     }
     hipLaunchKernelGGL((flat_gemm_kernel<NB, MODE>), dim3(blocks), dim3(256), lds, s, p);
     return nsg_check_launch("flat_gemm_kernel");

@@ -545,12 +545,10 @@ int launch_one(const GatherGemmParams &p, hipStream_t s)
     const int64_t gx = ntm * ntn;
     if (gx <= 0 || gx > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: grid too large");
     dim3 grid((unsigned)gx, MODE == 0 ? 1 : 4, 1);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU, DMA>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "gather_gemm: cannot reserve %zu bytes of LDS", lds);
-        attr_set = true;
+    static LdsOptIn once;   // > 64 KiB of dynamic LDS must be opted into once per kernel and device
+    if (lds > 65536) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU, DMA>)}, lds, "gather_gemm");
+        if (rc != NSG_OK) return rc;
     }
     hipLaunchKernelGGL((gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU, DMA>), grid, dim3(64 * WM * WN), lds, s, p);
     return nsg_check_launch("gather_gemm");
@@ -610,6 +608,9 @@ int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
 {
     GatherGemmParams p = p_in;
+    const uint64_t rows = (uint64_t)p.B * p.RH * p.RW;       // callers form p.M in 32 bits
+    if (rows > 0x7fffffffull || (uint64_t)(int64_t)p.M != rows)
+        return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: %llu output rows overflow 31 bits (split the batch)", (unsigned long long)rows);
     if (p.M <= 0) return NSG_OK;
     const int epv = p.in_dtype == NSG_BF16 ? 8 : 4;
     const uint64_t es = p.in_dtype == NSG_BF16 ? 2 : 4;
@@ -617,6 +618,11 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
     const uint64_t w_bytes = (uint64_t)(p.mode == 0 ? p.KH * p.KW : 16) * p.CO * p.CI * es;
     if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull)   // 32-bit byte offsets; 0xfffffff0 is the kernel's "reads as zero" offset
         return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: operand of %llu bytes (limit 4 GiB per tensor: split the batch)", (unsigned long long)in_bytes);
+    // output rows are addressed by 32-bit ELEMENT offsets (rowoff; the fused add / ReLU-mask operands share them): a transposed
+    // conv's output is 4x its input, so it can pass the byte limits above and still not fit (B ~ 820 at D = 128, 80 x 1024)
+    const uint64_t out_elems = (uint64_t)p.B * p.OH * p.OW * p.CO;
+    if (out_elems >= 0x80000000ull)
+        return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: output of %llu elements (limit 2^31 per tensor: split the batch)", (unsigned long long)out_elems);
     if (p.KH > 15 || p.KW > 15) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: kernel extent above 15");
     if (p.epi_add || p.epi_mask) {
         const int epo = p.out_dtype == NSG_BF16 ? 8 : 4;

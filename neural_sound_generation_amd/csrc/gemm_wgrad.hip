@@ -733,12 +733,10 @@ int launch_wg1(const WgradParams &p, int nslab, hipStream_t s)
     const int ntaps = p.KH * p.KW;
     const int tiles = (int)(nsg_cdiv(p.A, TA) * nsg_cdiv(p.C, TC));
     dim3 grid(nslab, ntaps, tiles);
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_gemm_f32<TI, WM, WN, TM, TN, ONEHOT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
-        attr_set = true;
+    static LdsOptIn once;
+    if (lds > 65536) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&wgrad_gemm_f32<TI, WM, WN, TM, TN, ONEHOT>)}, lds, "wgrad");
+        if (rc != NSG_OK) return rc;
     }
     hipLaunchKernelGGL((wgrad_gemm_f32<TI, WM, WN, TM, TN, ONEHOT>), grid, dim3(256), lds, s, p);
     return nsg_check_launch("wgrad_gemm_f32");
@@ -752,15 +750,12 @@ int launch_wg_bf16(const WgradParams &p, int nslab, hipStream_t s)
     const int ntaps = p.KH * p.KW;
     const int tiles = (int)(nsg_cdiv(p.A, TA) * nsg_cdiv(p.C, TC));
     dim3 grid(nslab, ntaps, tiles);
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536) {
-        for (const void *f : {reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false>),
-                              reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, true>),
-                              reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false, true>)}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return nsg_fail((int)e, "wgrad: cannot reserve %zu bytes of LDS", lds);
-        }
-        attr_set = true;
+    static LdsOptIn once;
+    if (lds > 65536) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false>),
+                                             reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, true>),
+                                             reinterpret_cast<const void *>(&wgrad_gemm_bf16<WM, WN, TM, TN, false, true>)}, lds, "wgrad");
+        if (rc != NSG_OK) return rc;
     }
     if (p.q_mean) {
         if (p.relu_p || p.relu_q || p.KH * p.KW != 1 || p.pad || p.pad_w || p.stride != 1)

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
+#include <initializer_list>
 #include "nsg.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -107,6 +109,14 @@ int nsg_check_launch(const char *what);
     do {                                                \
         if (!(cond)) return nsg_fail((code), __VA_ARGS__); \
     } while (0)
+
+// More than 64 KiB of dynamic LDS must be opted into per kernel AND per device.  One LdsOptIn per call site (a function-local
+// static: constant-initialised, so thread-safe) remembers the devices already done as a bit mask; racing first calls both
+// set the (idempotent) attribute.  No lock, no other global state.
+struct LdsOptIn {
+    std::atomic<uint64_t> devices{0};
+};
+int nsg_lds_opt_in(LdsOptIn &once, std::initializer_list<const void *> kernels, size_t lds_bytes, const char *what);
 
 static inline bool nsg_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool nsg_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -7,7 +7,7 @@
 // with c2/x2 summed in ATen's vector-lane order, and torch.min keeps the first minimal index.
 // v_mfma_f32_32x32x2_f32 IS a k-ordered fmaf chain (one rounding per product, no wider
 // accumulator), so feeding it d = 2s (lanes 0-31) and d = 2s+1 (lanes 32-63) at step s reproduces
-// the chain exactly on the matrix pipe.  tests/test_gpu_vq.py checks MFMA == VALU chain bit for bit
+// the chain exactly on the matrix pipe.  tests/test_gpu_ops.py checks MFMA == VALU chain bit for bit
 // (nsg_debug_dot) and the indices against fixtures generated from the reference.
 #include "nsg_common.h"
 #include <math.h>
@@ -362,14 +362,11 @@ int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const 
     const size_t lds = lds_e > lds_x ? lds_e : lds_x;
     const int64_t nb = nsg_cdiv(N, 128);
     if (nb > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "vq_forward: too many rows");
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536 - 1024) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_forward_kernel<DP, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_forward_kernel<DP, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess || e2 != hipSuccess) return nsg_fail((int)(e1 != hipSuccess ? e1 : e2), "vq_forward: cannot reserve %zu bytes of LDS", lds);
-        attr_set = true;
+    static LdsOptIn once;
+    if (lds > 65536 - 1024) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&vq_forward_kernel<DP, true>),
+                                             reinterpret_cast<const void *>(&vq_forward_kernel<DP, false>)}, lds, "vq_forward");
+        if (rc != NSG_OK) return rc;
     }
     if (mfma)
         hipLaunchKernelGGL((vq_forward_kernel<DP, true>), dim3((unsigned)nb), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin);

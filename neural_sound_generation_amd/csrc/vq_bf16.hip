@@ -205,12 +205,10 @@ int launch(const float *x, const bf16_t *ehi, const bf16_t *elo, const float *e,
     const size_t lds = (size_t)2 * 2 * 32 * (DP * 2 + 16);
     const int64_t nb = nsg_cdiv(N, 128);
     if (nb > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "vq_forward_bf16x3: too many rows");
-    static bool attr_set = false;
-    if (!attr_set && lds > 65536 - 1024) {
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_forward_bf16x3_kernel<NKS>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (er != hipSuccess) return nsg_fail((int)er, "vq_forward_bf16x3: cannot reserve %zu bytes of LDS", lds);
-        attr_set = true;
+    static LdsOptIn once;
+    if (lds > 65536 - 1024) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&vq_forward_bf16x3_kernel<NKS>)}, lds, "vq_forward_bf16x3");
+        if (rc != NSG_OK) return rc;
     }
     hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
     return nsg_check_launch("vq_forward_bf16x3_kernel");

@@ -49,3 +49,21 @@ def test_size_queries():
     assert lib.nsg_conv_workspace_bytes(ctypes.byref(bad)) == 0
     assert lib.nsg_bn_workspace_bytes(5120, 128) > 0
     assert lib.nsg_reduce_workspace_bytes(10) >= 8
+
+
+def test_gather_gemm_rejects_tensors_past_its_32_bit_row_offsets():
+    """A transposed conv's output is 4x its input: (820, 20, 256, 128) bf16 passes the 4 GiB operand limit but the
+    (820, 40, 512, 128) output has more than 2^31 elements, which the kernel's int row offsets cannot address
+    (ADVICE r1).  The launcher must refuse before touching the GPU -- fake pointers, no allocation, runs on CPU."""
+    lib = _lib.load()
+    fake, null = ctypes.c_void_p(0x10000), ctypes.c_void_p(0)
+    d = _lib.ConvDesc(820, 20, 256, 128, 40, 512, 128, 4, 2, 1, 1, _lib.NSG_BF16)
+    assert lib.nsg_conv_forward(ctypes.byref(d), fake, fake, null, fake, 0, fake, 1 << 30, null) == -2
+    assert b"2^31" in lib.nsg_last_error_string()
+    # the data gradient of Conv2d(128, 128, 4, 2, 1) writes the same 4x tensor (with the fused add / mask operands on the same offsets)
+    d = _lib.ConvDesc(820, 40, 512, 128, 20, 256, 128, 4, 2, 1, 0, _lib.NSG_BF16)
+    assert lib.nsg_conv_dgrad_relu_add(ctypes.byref(d), fake, fake, fake, fake, fake, 0, fake, 1 << 30, null) == -2
+    assert b"2^31" in lib.nsg_last_error_string()
+    # one clip fewer fits: the guard must not fire early (it would launch, so only the pure checks are exercised up to here)
+    d = _lib.ConvDesc(1 << 20, 20, 256, 128, 40, 512, 128, 4, 2, 1, 1, _lib.NSG_BF16)   # the row count itself overflows
+    assert lib.nsg_conv_forward(ctypes.byref(d), fake, fake, null, fake, 0, fake, 1 << 30, null) == -2
