@@ -65,6 +65,31 @@ def cpu_baseline(D, K, T, threads, batch=4, warmup=1, steps=3):
     return batch * T / dt, dt
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: start the N ranks ourselves, one fresh process per GPU with torchrun's
+    environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  This parent makes no GPU call before or after (a
+    process that has initialised the GPU must not exec, and device_count() does not initialise it on this image); rank 0
+    prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "NSG_DEVICE_INDEX" not in os.environ:
+        print(f"[bench] --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +107,8 @@ def main():
     ap.add_argument("--no-second-mode", action="store_true", help="skip the short run of the other compute mode")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     from neural_sound_generation_amd import distributed as nsg_dist, models as M, ops
     from neural_sound_generation_amd.train import FusedTrainStep

@@ -141,6 +141,12 @@ NSG_API int nsg_index_add_rows_bf16x2(const int64_t *idx, const float *g, int64_
 NSG_API int nsg_gather_rows(const float *e, const int64_t *idx, int64_t N, int32_t D, int32_t K, float *out,
                             void *stream);
 
+/* Codebook gradient of loss_vq = mse(codebook[idx], sg(z_e)) (src/train.py:131 through index_select, src/models.py:137)
+ * from per-code statistics instead of an (N, D) gradient tensor: with n[k] rows assigned to code k and s[k] = their sum
+ * (nsg_index_add_rows over z_e with counts),  out[k][:] = scale * (n[k] * e[k][:] - s[k][:]),  scale = 2 / (N*D). */
+NSG_API int nsg_codebook_grad_from_sums(const float *e, const float *n, const float *s, int32_t K, int32_t D, float scale,
+                                        float *out, void *stream);
+
 /* EMA codebook update (extension, not in the reference; VQ-VAE paper appendix A.1):
  *   ema_n = decay*ema_n + (1-decay)*n;  ema_s = decay*ema_s + (1-decay)*s;
  *   e[k] = ema_s[k] / ((ema_n[k]+eps) / (sum(ema_n) + K*eps) * sum(ema_n)).
@@ -357,6 +363,10 @@ NSG_API int nsg_convert(const void *src, int32_t src_dtype, void *dst, int32_t d
 
 /* dx = g * (1 - y*y): backward of nn.Tanh (models.py:183) from its output y. */
 NSG_API int nsg_tanh_backward(const float *g, const float *y, float *dx, int64_t n, void *stream);
+
+/* *counters[i] += 1 for i < n: the `num_batches_tracked += 1` of every nn.BatchNorm2d a training-mode forward passes
+ * (src/models.py:151,154,166,180) as one launch per 32 counters.  `counters` is a HOST array of device pointers. */
+NSG_API int nsg_increment_counters(int64_t *const *counters, int32_t n, void *stream);
 
 /* y = a + b (b may be NULL -> copy). */
 NSG_API int nsg_add(const float *a, const float *b, float *y, int64_t n, void *stream);

@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256) void add_kernel(const float *a, const float *b
     }
 }
 
+// d loss_vq / d codebook from the per-code statistics of the encoder rows: out[k][d] = scale * (n[k] * e[k][d] - s[k][d])
+__global__ __launch_bounds__(256) void codebook_grad_from_sums_kernel(const float *__restrict__ e, const float *__restrict__ n,
+                                                                      const float *__restrict__ s, float *__restrict__ out, int64_t total,
+                                                                      int D, float scale)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i / D;
+        const float ne = e[i] * n[k];          // three separately rounded operations (-ffp-contract=off), as ATen's mul, sub_, mul_ did
+        out[i] = (ne - s[i]) * scale;
+    }
+}
+
+struct CounterPtrs {
+    int64_t *p[32];
+};
+__global__ void increment_counters_kernel(const CounterPtrs c, int n)
+{
+    const int i = threadIdx.x;
+    if (i < n) *c.p[i] += 1;
+}
+
 // block-level sum in double, fixed order: thread partials -> LDS -> thread 0 walks them
 __device__ __forceinline__ void block_sum_store(double part, double *dst)
 {
@@ -388,6 +409,31 @@ int nsg_add(const float *a, const float *b, float *y, int64_t n, void *stream)
     else
         hipLaunchKernelGGL((add_kernel<1>), dim3(ew_blocks(n)), dim3(256), 0, s, a, b, y, n);
     return nsg_check_launch("add_kernel");
+}
+
+int nsg_codebook_grad_from_sums(const float *e, const float *n, const float *s, int32_t K, int32_t D, float scale, float *out, void *stream)
+{
+    NSG_REQUIRE(e && n && s && out && K > 0 && D > 0, NSG_E_INVALID, "nsg_codebook_grad_from_sums: bad argument");
+    const int64_t total = (int64_t)K * D;
+    hipLaunchKernelGGL(codebook_grad_from_sums_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, e, n, s, out, total, (int)D, scale);
+    return nsg_check_launch("codebook_grad_from_sums_kernel");
+}
+
+int nsg_increment_counters(int64_t *const *counters, int32_t n, void *stream)
+{
+    NSG_REQUIRE(n >= 0 && (n == 0 || counters), NSG_E_INVALID, "nsg_increment_counters: bad argument");
+    for (int32_t i0 = 0; i0 < n; i0 += 32) {
+        CounterPtrs c = {};
+        const int m = n - i0 < 32 ? n - i0 : 32;
+        for (int i = 0; i < m; ++i) {
+            NSG_REQUIRE(counters[i0 + i], NSG_E_INVALID, "nsg_increment_counters: null counter");
+            c.p[i] = counters[i0 + i];
+        }
+        hipLaunchKernelGGL(increment_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c, m);
+        const int rc = nsg_check_launch("increment_counters_kernel");
+        if (rc) return rc;
+    }
+    return NSG_OK;
 }
 
 int nsg_add_per_clip(const float *x, const float *rows, void *y, int32_t B, int64_t rows_per_clip, int32_t C, int32_t y_dtype,

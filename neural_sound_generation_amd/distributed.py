@@ -42,6 +42,30 @@ def broadcast_flat(flat: torch.Tensor, src: int = 0, group=None):
         dist.broadcast(flat, src=src, group=group)
 
 
+def state_outside(model, opt) -> list:
+    """Tensors of `model`'s state that do NOT live in `opt`'s flat parameter bucket: buffers (BatchNorm running statistics and
+    counters, the EMA codebook's ema_count / ema_sum) and parameters the optimiser skips (requires_grad=False: an EMA-trained
+    codebook).  state_dict order, so every rank lists the same tensors."""
+    lo = opt.flat_param.data_ptr()
+    hi = lo + opt.flat_param.numel() * opt.flat_param.element_size()
+    return [t for t in model.state_dict(keep_vars=True).values() if not (lo <= t.data_ptr() < hi)]
+
+
+def broadcast_tensors_packed(tensors, src: int = 0, group=None):
+    """Broadcast rank `src`'s values of `tensors` (any dtypes) as ONE flat message: each is widened to float64 (exact for fp32
+    and for the int64 step counters below 2^53), sent together, and copied back in place."""
+    if world_size(group) == 1 or not tensors:
+        return
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float64) for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.detach().copy_(flat[off:off + n].view(t.shape).to(t.dtype))
+            off += n
+
+
 def allreduce_sum_(flat: torch.Tensor, group=None, async_op: bool = False):
     """In-place sum over ranks of one flat bucket; returns the work handle when async."""
     if world_size(group) == 1:

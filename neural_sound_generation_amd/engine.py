@@ -83,7 +83,7 @@ FUSED_1X1 = _os.environ.get("NSG_FUSED_1X1", "1") == "1"
 
 
 # num_batches_tracked += 1 per BatchNorm is ten tiny launches a step; a fused step collects the counters here
-# and bumps them with one torch._foreach_add_ (deferred_batch_counters)
+# and bumps them with one launch of the library's own kernel (deferred_batch_counters -> nsg_increment_counters)
 _nbt_pending = None
 
 
@@ -98,7 +98,7 @@ class deferred_batch_counters:
         global _nbt_pending
         pending, _nbt_pending = _nbt_pending, self._outer
         if pending and exc[0] is None:
-            torch._foreach_add_(pending, 1)
+            ops.increment_counters(pending)
         return False
 
 
@@ -108,7 +108,7 @@ def _bump(bn: "BNParams"):
     if _nbt_pending is not None:
         _nbt_pending.append(bn.num_batches_tracked)
     else:
-        bn.num_batches_tracked += 1
+        ops.increment_counters([bn.num_batches_tracked])
 
 
 def _conv_bn(d, x, wf, conv: ConvParams, bn: BNParams, training: bool, flags=0):

@@ -148,18 +148,51 @@ def rowsumsq(v):
     return out
 
 
-def index_add_rows(idx, g2d, K, want_counts=False, impl="f32"):
+def index_add_rows(idx, g2d, K, want_counts=False, impl="f32", out=None, counts=None):
     """out[k] = sum of rows of g2d whose idx == k; deterministic.  impl: "f32" (fp32 matrix pipe, exact products) or
-    "bf16x2" (the bf16 compute mode: rows split into bf16 hi + lo, relative error of a sum ~2^-17)."""
+    "bf16x2" (the bf16 compute mode: rows split into bf16 hi + lo, relative error of a sum ~2^-17).
+    out (K, D) / counts (K,): optional preallocated fp32 destinations (e.g. views of a communication buffer)."""
     _chk(idx, "idx", torch.int64); _chk(g2d, "g")
     N, D = g2d.shape
-    out = torch.empty(K, D, dtype=torch.float32, device=g2d.device)
-    counts = torch.empty(K, dtype=torch.float32, device=g2d.device) if want_counts else None
+    if out is None:
+        out = torch.empty(K, D, dtype=torch.float32, device=g2d.device)
+    elif _chk(out, "out").shape != (K, D):
+        raise _lib.NsgError(f"index_add_rows: out has shape {tuple(out.shape)}, expected {(K, D)}")
+    if counts is not None:
+        if _chk(counts, "counts").shape != (K,):
+            raise _lib.NsgError(f"index_add_rows: counts has shape {tuple(counts.shape)}, expected {(K,)}")
+        want_counts = True
+    elif want_counts:
+        counts = torch.empty(K, dtype=torch.float32, device=g2d.device)
     nb = _lib.query("nsg_index_add_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
     ws = WS.get(nb, g2d.device)
     _lib.call("nsg_index_add_rows_bf16x2" if impl == "bf16x2" else "nsg_index_add_rows", _p(idx), _p(g2d), c_int64(N), c_int32(D),
               c_int32(K), _p(out), _p(counts), _p(ws), c_size_t(nb), _stream())
     return (out, counts) if want_counts else out
+
+
+def codebook_grad_from_sums(codebook, n, s, scale, out):
+    """out[k] = scale * (n[k] * codebook[k] - s[k]): the codebook gradient of mse(codebook[idx], sg(z)) from the per-code
+    counts n (K,) and sums s (K, D) of the rows z assigned to each code (index_add_rows(..., want_counts=True))."""
+    _chk(codebook, "codebook"); _chk(n, "n"); _chk(s, "s"); _chk(out, "out")
+    K, D = codebook.shape
+    if n.numel() != K or s.numel() != K * D or out.numel() != K * D:
+        raise _lib.NsgError("codebook_grad_from_sums: n, s and out must match the codebook's (K, D)")
+    _lib.call("nsg_codebook_grad_from_sums", _p(codebook), _p(n), _p(s), c_int32(K), c_int32(D), c_float(scale), _p(out), _stream())
+    return out
+
+
+def increment_counters(counters):
+    """counters: int64 GPU scalars (BatchNorm2d.num_batches_tracked), each += 1, one launch."""
+    n = len(counters)
+    if n == 0:
+        return
+    arr = (c_void_p * n)()
+    for i, t in enumerate(counters):
+        if not t.is_cuda or t.dtype != torch.int64 or t.numel() != 1:
+            raise _lib.NsgError("increment_counters: expected int64 GPU scalars")
+        arr[i] = t.data_ptr()
+    _lib.call("nsg_increment_counters", ctypes.cast(arr, c_void_p), c_int32(n), _stream())
 
 
 def gather_rows(codebook, idx):

@@ -42,7 +42,25 @@ class FlatAdam(torch.optim.Optimizer):
                 gview = self.flat_grad[off:off + p.numel()].view_as(p)
                 p.grad = gview                     # autograd accumulates in place into the bucket
                 self.grad_views.append(gview)
+        self.flat_comm = self.flat_grad          # what a data-parallel step all-reduces: [gradients | reserved tail]
         self.step_count = 0
+
+    @torch.no_grad()
+    def reserve_tail(self, n_floats: int) -> torch.Tensor:
+        """Room for `n_floats` fp32 values BEHIND the gradients in the same allocation: per-step statistics that must be
+        summed over ranks (the EMA codebook's per-code counts and sums) then ride in the gradients' one all-reduce
+        (SURVEY.md section 8e).  Re-binds every p.grad to the new storage; returns the tail view."""
+        pad = (int(n_floats) + _ALIGN - 1) // _ALIGN * _ALIGN
+        comm = torch.zeros(self.total + pad, dtype=torch.float32, device=self.flat_grad.device)
+        comm[:self.total].copy_(self.flat_grad)
+        self.flat_comm = comm
+        self.flat_grad = comm[:self.total]
+        self.grad_views = []
+        for p, off in zip(self._params, self.offsets):
+            gview = self.flat_grad[off:off + p.numel()].view_as(p)
+            p.grad = gview
+            self.grad_views.append(gview)
+        return comm[self.total:self.total + int(n_floats)]
 
     def zero_grad(self, set_to_none: bool = False):
         # the views must survive: never set to None

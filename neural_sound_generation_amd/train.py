@@ -35,10 +35,21 @@ class FusedTrainStep:
         self.group = process_group
         self.opt = optimizer if optimizer is not None else FlatAdam(model.parameters(), lr=lr, betas=betas, eps=eps)
         self.world = nsg_dist.world_size(process_group)
-        if self.world > 1:
-            nsg_dist.broadcast_flat(self.opt.flat_param, 0, process_group)
         self.dtype = getattr(model, "compute_dtype", torch.float32)
         self.ema = getattr(model.codebook, "ema_decay", None) is not None
+        if self.world > 1:
+            # every replica starts from rank 0's state: the parameter bucket, and -- packed into one flat tensor, one more
+            # broadcast -- everything outside it: BatchNorm running statistics and counters, an EMA-trained codebook
+            # (requires_grad=False keeps it out of the bucket) with its ema_count / ema_sum buffers
+            nsg_dist.broadcast_flat(self.opt.flat_param, 0, process_group)
+            nsg_dist.broadcast_tensors_packed(nsg_dist.state_outside(model, self.opt), 0, process_group)
+        if self.ema:
+            # [n (K, padded to 256 bytes) | sum z (K x D)] lives BEHIND the gradients: ONE all-reduce carries both
+            K, D = model.codebook.embedding.weight.shape
+            self._n_pad = (K + 63) // 64 * 64
+            tail = self.opt.reserve_tail(self._n_pad + K * D)
+            self.ema_n = tail[:K]
+            self.ema_s = tail[self._n_pad:].view(K, D)
         # bf16 mode: the codebook scatter-add on the bf16 matrix pipe (rows split hi + lo); fp32 mode: exact products
         self.scatter_impl = "bf16x2" if self.dtype == torch.bfloat16 else "f32"
         self.encP = engine.encoder_params(model.encoder)
@@ -99,18 +110,16 @@ class FusedTrainStep:
             loss_vq, dz = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
                                                 grad_dtype=self.dtype)
             dz = dz.view(ze.shape)
-            s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
-            if self.ema:
-                self.ema_stats = torch.cat([n, s.view(-1)])
+            if self.ema:    # per-code counts and sums straight into the communication buffer's tail
+                ops.index_add_rows(idx, ze.view(-1, D), K, impl=self.scatter_impl, out=self.ema_s, counts=self.ema_n)
             else:   # d loss_vq / d e_k = 2/numel * sum over the rows assigned to k of (e_k - z) = 2/numel * (n_k e_k - s_k)
-                torch.mul(self.codebook.detach(), n.unsqueeze(1), out=self.g_code.view(K, D))
-                self.g_code.view(K, D).sub_(s).mul_(2.0 / ze.numel())
+                s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
+                ops.codebook_grad_from_sums(self.codebook.detach(), n, s, 2.0 / ze.numel(), out=self.g_code)
         elif self.ema:
             # EMA codebook (extension): no codebook gradient; per-code counts and sums of the assigned
             # encoder rows are the statistics every rank contributes (summed over ranks in step())
             loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False, grad_dtype=self.dtype)
-            s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
-            self.ema_stats = torch.cat([n, s.view(-1)])       # ONE buffer -> ONE small all-reduce
+            ops.index_add_rows(idx, ze.view(-1, D), K, impl=self.scatter_impl, out=self.ema_s, counts=self.ema_n)
         else:
             loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, grad_dtype=self.dtype)
             self._codebook_grad(idx, dq.view(-1, D), K)
@@ -153,21 +162,20 @@ class FusedTrainStep:
         else:
             losses = self.forward_backward(c, g)
         if self.world > 1:
-            nsg_dist.allreduce_sum_(self.opt.flat_grad, self.group)
-            if self.ema:
-                nsg_dist.allreduce_sum_(self.ema_stats, self.group)
+            # ONE collective per step: the gradient bucket, and behind it (EMA mode) the per-code counts and sums
+            nsg_dist.allreduce_sum_(self.opt.flat_comm, self.group)
         self.opt.step(grad_scale=1.0 / self.world)
         if self.ema:
-            self.apply_ema(self.ema_stats)
+            self.apply_ema()
         return losses
 
     @torch.no_grad()
-    def apply_ema(self, stats: torch.Tensor):
-        """stats = [n (K) | s (K*D)] summed over ranks: identical update on every rank."""
+    def apply_ema(self, n: torch.Tensor | None = None, s: torch.Tensor | None = None):
+        """n (K,), s (K, D): per-code counts and sums of the encoder rows, summed over ranks (default: this step's, as
+        left in the communication buffer by the all-reduce): the identical update on every rank."""
         cb = self.model.codebook
-        K, D = self.codebook.shape
-        ops.vq_ema_update(self.codebook.data, cb.ema_count, cb.ema_sum, stats[:K].contiguous(), stats[K:].view(K, D).contiguous(),
-                          decay=cb.ema_decay, eps=cb.ema_eps)
+        ops.vq_ema_update(self.codebook.data, cb.ema_count, cb.ema_sum, self.ema_n if n is None else n.contiguous(),
+                          self.ema_s if s is None else s.contiguous(), decay=cb.ema_decay, eps=cb.ema_eps)
 
 
 def vqvae_loss_terms(c, x_tilde, z_e_x, z_q_x):

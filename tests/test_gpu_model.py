@@ -302,16 +302,21 @@ def test_ema_codebook_mode_and_data_parallel_identity():
     w0 = model.codebook.embedding.weight.detach().clone()
     n0, s0 = model.codebook.ema_count.clone(), model.codebook.ema_sum.clone()
     step.forward_backward(c)
-    stats = step.ema_stats.clone()
+    stats_n, stats_s = step.ema_n.clone(), step.ema_s.clone()
+    # the statistics sit directly behind the gradients, inside the ONE buffer a data-parallel step all-reduces
+    comm = step.opt.flat_comm
+    assert comm.data_ptr() == step.opt.flat_grad.data_ptr() and comm.numel() > step.opt.flat_grad.numel()
+    assert step.ema_s.data_ptr() + step.ema_s.numel() * 4 <= comm.data_ptr() + comm.numel() * 4
+    assert step.ema_n.data_ptr() >= comm.data_ptr() + step.opt.flat_grad.numel() * 4
     idx = step.last_indices.cpu()
     # statistics against torch on the same encoder output
     ze = model.encoder(c).detach()
     zflat = ze.permute(0, 2, 3, 1).reshape(-1, D).cpu()
     n_ref, s_ref = O.ema_stats(zflat, idx, K)
-    assert torch.equal(stats[:K].cpu(), n_ref)
-    np.testing.assert_allclose(stats[K:].view(K, D).cpu().numpy(), s_ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(stats_n.cpu(), n_ref)
+    np.testing.assert_allclose(stats_s.cpu().numpy(), s_ref.numpy(), rtol=1e-5, atol=1e-5)
     w_ref, n1_ref, s1_ref = O.ema_update(w0.cpu(), n0.cpu(), s0.cpu(), n_ref, s_ref, decay=0.99)
-    step.apply_ema(stats)
+    step.apply_ema(stats_n, stats_s)
     np.testing.assert_allclose(model.codebook.embedding.weight.detach().cpu().numpy(), w_ref.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(model.codebook.ema_count.cpu().numpy(), n1_ref.numpy(), rtol=1e-6)
     # data-parallel identity: two half-batches -> summed statistics == full-batch statistics (given the same z_e)
