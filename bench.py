@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense bf16
+PEAK_HBM_GBPS = 8000.0          # same guide: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
 def flops_per_frame(D: int, K: int) -> float:
@@ -106,11 +107,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-mode", action="store_true", help="skip the short run of the other compute mode")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs[3] (K=8192, D=256)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
-    from neural_sound_generation_amd import distributed as nsg_dist, models as M, ops
+    from neural_sound_generation_amd import _lib, distributed as nsg_dist, models as M, ops
     from neural_sound_generation_amd.train import FusedTrainStep
 
     rank, world, local = nsg_dist.init_from_env()
@@ -125,19 +127,20 @@ def main():
     dev = torch.device("cuda", local)
     D, K, T, B = args.dim, args.z_dim, args.frames, args.batch
 
-    def run_mode(dtype_name, steps, warmup, use_timer):
-        """Time `steps` training steps of the given compute mode; returns (value, ms_per_step, losses, timer summary)."""
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def run_mode(dtype_name, steps, warmup, use_timer, D=D, K=K, B=B, census_steps=0):
+        """Time `steps` training steps of the given compute mode.  Returns dict(value, ms, losses, gather (the dominant
+        kernel's HIP-event summary over the timed region), census (per-kernel summary of `census_steps` extra steps taken
+        AFTER the timed region with every entry-point call bracketed by events))."""
         torch.manual_seed(1)                       # src/main.py:43,71 -- identical init on every rank
         cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
         model = M.VQVAE(1, D, K, compute_dtype=cdtype).to(dev).train()
         step = FusedTrainStep(model, lr=1e-3, beta=1.0)
         c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
-
-        def sync():
-            if world > 1:
-                torch.distributed.barrier()
-            torch.cuda.synchronize()
-
         for _ in range(warmup):
             step.step(c)
         timer = None
@@ -155,23 +158,77 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
-        value = world * B * T * steps / elapsed
-        summ = timer.summary().get("gather_gemm_f32") if timer is not None else None
+        out = {"value": world * B * T * steps / elapsed, "ms": elapsed / steps * 1e3, "losses": [float(x.item()) for x in losses],
+               "gather": timer.summary().get("gather_gemm_f32") if timer is not None else None, "census": None}
+        if census_steps > 0 and rank == 0:
+            cen = ops.KernelTimer()
+            _lib.CENSUS = cen
+            for _ in range(census_steps):
+                step.forward_backward(c)           # (no collective inside: the other ranks need not take part)
+                step.opt.step()
+            torch.cuda.synchronize()
+            _lib.CENSUS = None
+            out["census"] = {k: dict(v, per_step=v["launches"] / census_steps) for k, v in cen.summary().items()}
         del step, model
         torch.cuda.empty_cache()
-        return value, elapsed / steps * 1e3, [float(x.item()) for x in losses], summ
+        return out
 
-    value, ms_per_step, loss_triple, s = run_mode(args.dtype, args.steps, args.warmup, not args.no_kernel_timer)
+    def kernel_table(census, dtype_name, ms_per_step):
+        """One row per kernel group of the step: launches per step, HIP-event time per launch, algorithmic work per launch
+        (FLOP for the MFMA-bound contractions, bytes moved once per pass the algorithm needs for the HBM-bound ones;
+        ops.py states each call's figure where it is launched), achieved rate, fraction of the bounding peak."""
+        rows = []
+        for label, v in sorted(census.items(), key=lambda kv: -kv[1]["total_ms"]):
+            hbm = v["bytes_per_launch"] > 0
+            if not hbm and v["flops_per_launch"] <= 0:
+                bound, ach, peak, unit = None, None, None, None
+            elif hbm:
+                bound, ach, peak, unit = "hbm", v["tbps"] * 1e3, PEAK_HBM_GBPS, "GB/s"
+            else:
+                f32_pipe = dtype_name == "f32" or "fp32" in label or "f32" in label
+                bound, ach, peak, unit = "mfma", v["tflops"], (PEAK_F32_MFMA_TFLOPS if f32_pipe else PEAK_BF16_MFMA_TFLOPS), "TFLOP/s"
+            rows.append({"kernel": label, "per_step": round(v["per_step"], 2), "us_per_launch": round(v["avg_ms"] * 1e3, 1),
+                         "share_of_step": round(v["avg_ms"] * v["per_step"] / ms_per_step, 4), "bound": bound,
+                         "gflop_per_launch": round(v["flops_per_launch"] / 1e9, 3) if not hbm and bound else None,
+                         "mb_per_launch": round(v["bytes_per_launch"] / 1e6, 2) if hbm else None,
+                         "achieved": round(ach, 1) if ach is not None else None, "unit": unit,
+                         "frac": round(ach / peak, 4) if ach is not None else None})
+        return rows
+
+    main_run = run_mode(args.dtype, args.steps, args.warmup, not args.no_kernel_timer, census_steps=0 if args.no_kernel_timer else 3)
+    value, ms_per_step, loss_triple, s = main_run["value"], main_run["ms"], main_run["losses"], main_run["gather"]
     other = None
     if not args.no_second_mode:
         # the other compute mode, same shapes, a short run: fp32 = parity mode, bf16 = throughput mode
         od = "bf16" if args.dtype == "f32" else "f32"
-        ov, oms, ol, osum = run_mode(od, max(3, args.steps // 4), 2, not args.no_kernel_timer)
-        other = {"dtype": od, "value": round(ov, 1), "unit": "mel-frames/s", "ms_per_step": round(oms, 3), "losses": ol}
-        if osum:
+        o = run_mode(od, max(3, args.steps // 4), 2, not args.no_kernel_timer, census_steps=0 if args.no_kernel_timer else 2)
+        other = {"dtype": od, "value": round(o["value"], 1), "unit": "mel-frames/s", "ms_per_step": round(o["ms"], 3), "losses": o["losses"]}
+        if o["gather"]:
             opeak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
-            other["roofline"] = {"bound": "mfma", "kernel": "gather_gemm (%s operands)" % od, "achieved": round(osum["tflops"], 2),
-                                 "peak": opeak, "unit": "TFLOP/s", "frac": round(osum["tflops"] / opeak, 4)}
+            other["roofline"] = {"bound": "mfma", "kernel": "gather_gemm (%s operands)" % od, "achieved": round(o["gather"]["tflops"], 2),
+                                 "peak": opeak, "unit": "TFLOP/s", "frac": round(o["gather"]["tflops"] / opeak, 4),
+                                 "step_frac": round(o["value"] * flops_per_frame(D, K) / 1e12 / opeak, 4)}
+            if o["census"]:
+                other["roofline"]["kernels"] = kernel_table(o["census"], od, o["ms"])
+    other_configs = None
+    if not args.no_other_configs and world == 1 and (D, K) == (128, 512):
+        # BASELINE configs[3]: the large codebook (K = 8192, D = 256), 16 clips -- the config that stresses the distance
+        # contraction + argmin; both searches timed: the bit-exact fp32 one (parity mode) and the bf16x3 one (bf16 mode)
+        other_configs = []
+        for od in ("bf16", "f32"):
+            o = run_mode(od, 5, 2, False, D=256, K=8192, B=16, census_steps=2)
+            peak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
+            ent = {"workload": "BASELINE configs[3]: VQVAE(1, dim=256, z_dim=8192), 16 clips of 80-mel x %d frames, train step" % T,
+                   "dtype": od, "value": round(o["value"], 1), "unit": "mel-frames/s", "ms_per_step": round(o["ms"], 3), "losses": o["losses"],
+                   "algorithmic_tflops": round(o["value"] * flops_per_frame(256, 8192) / 1e12, 2),
+                   "step_frac": round(o["value"] * flops_per_frame(256, 8192) / 1e12 / peak, 4)}
+            if o["census"]:
+                rows = kernel_table(o["census"], od, o["ms"])
+                vq = [r for r in rows if r["kernel"].startswith("vq_forward")]
+                if vq:
+                    ent["vq_forward"] = vq[0]
+                ent["kernels"] = rows[:8]
+            other_configs.append(ent)
 
     if rank == 0:
         roof = None
@@ -190,7 +247,13 @@ def main():
                         "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
                         "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/)", "launches": s["launches"], "avg_launch_ms": round(s["avg_ms"], 4),
                         "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
-                        "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3)}
+                        "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3),
+                        # the whole step against the same peak: algorithmic FLOP per second / MFMA peak
+                        "step_frac": round(value / world * flops_per_frame(D, K) / 1e12 / peak, 4)}
+                if main_run["census"]:
+                    roof["kernels"] = kernel_table(main_run["census"], args.dtype, ms_per_step)
+                    roof["kernels_note"] = ("per-kernel rows: HIP events around every C-ABI call over 3 extra steps taken right after the timed "
+                                            "region (same process, same tensors); the headline row above is timed INSIDE the timed region")
         cpu = None
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is taken at N = 1 only
             threads = host_threads()
@@ -211,7 +274,7 @@ def main():
                                   "parity bar (bit-exact code indices, losses within 1e-5 of the reference CPU path) is met by the fp32 mode "
                                   "timed in this same run (other_mode)") if args.dtype == "bf16" else
                                  "fp32 parity mode: bit-exact code indices, losses within 1e-5 of the reference CPU path (tests/)"},
-            "roofline": roof, "cpu_baseline": cpu, "other_mode": other,
+            "roofline": roof, "cpu_baseline": cpu, "other_mode": other, "other_configs": other_configs,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -148,10 +148,31 @@ def load():
     return lib
 
 
+# Optional per-call census for bench.py's roofline table: when CENSUS is set (an object with begin() / end(label, start,
+# flops, nbytes)), every entry-point call is bracketed by events on the launch stream.  A wrapper that knows the call's
+# algorithmic work announces it with tag(label, flops, nbytes) right before the call; untagged calls go under their C name.
+CENSUS = None
+_TAG = None
+
+
+def tag(label: str, flops: float = 0.0, nbytes: float = 0.0):
+    global _TAG
+    if CENSUS is not None:
+        _TAG = (label, float(flops), float(nbytes))
+
+
 def call(name: str, *args):
     """Call a status-returning entry point; raise with the library's message on failure."""
+    global _TAG
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if CENSUS is not None:
+        t, _TAG = _TAG, None
+        start = CENSUS.begin()
+        rc = getattr(lib, name)(*args)
+        label, fl, nb = t if t is not None else (name, 0.0, 0.0)
+        CENSUS.end(label, start, fl, nb)
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.nsg_last_error_string()
         raise NsgError(f"{name} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -38,6 +38,10 @@ class _Stack(Function):
         ctx.bundle = bundle
         ctx.training = training
         ctx.dtype = dtype
+        # The backward reads some parameters again (BatchNorm scales, the 1x1 weights): registering them with autograd makes
+        # `ctx.saved_tensors` raise the usual "modified by an inplace operation" error if an optimiser stepped in between,
+        # as the reference's per-layer autograd would, instead of silently differentiating against the new values.
+        ctx.save_for_backward(*params)
         if fwd is engine.resblock_forward:
             y, saved = fwd(ops.convert(to_nhwc(x.detach()), dtype, relu=True), bundle, training, out_dtype=torch.float32)
         else:
@@ -49,14 +53,18 @@ class _Stack(Function):
 class EncoderFn(Function):
     @staticmethod
     def forward(ctx, x, bundle, training, dtype, *params):
+        if ctx.needs_input_grad[0]:
+            # the reference can differentiate w.r.t. the mel image; this path does not build that gradient (the input layer's
+            # conv output is never stored) -- say so instead of returning None
+            raise RuntimeError("the encoder input is data: a gradient w.r.t. the mel batch is not implemented (pass c.detach())")
         return _Stack._run_forward(ctx, engine.encoder_forward, bundle, x, training, params, dtype)
 
     @staticmethod
     def backward(ctx, dz):
         if not ctx.training:
             raise RuntimeError("backward through the encoder in eval() mode is not implemented")
+        ctx.saved_tensors                      # version check of the parameters (see _run_forward)
         grads = engine.encoder_backward(to_nhwc(dz), ctx.saved, ctx.bundle)
-        ctx.saved = None
         return (None, None, None, None) + tuple(grads)
 
 
@@ -69,8 +77,8 @@ class DecoderFn(Function):
     def backward(ctx, dxt):
         if not ctx.training:
             raise RuntimeError("backward through the decoder in eval() mode is not implemented")
+        ctx.saved_tensors
         dz, grads = engine.decoder_backward(to_nhwc(dxt), ctx.saved, ctx.bundle, need_dz=ctx.needs_input_grad[0])
-        ctx.saved = None
         if dz is not None:
             dz = to_nchw_view(ops.convert(dz, torch.float32))
         return (dz, None, None, None) + tuple(grads)
@@ -85,8 +93,8 @@ class ResBlockFn(Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("backward through a ResBlock in eval() mode is not implemented")
+        ctx.saved_tensors
         dx, grads = engine.resblock_backward(ops.convert(to_nhwc(dy), ctx.dtype), ctx.saved, ctx.bundle, need_dx=ctx.needs_input_grad[0])
-        ctx.saved = None
         if dx is not None:
             dx = to_nchw_view(ops.convert(dx, torch.float32))
         return (dx, None, None, None) + tuple(grads)

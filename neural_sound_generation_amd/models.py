@@ -92,10 +92,18 @@ class ResBlock(nn.Module):
         )
 
     def forward(self, x):
-        # y = relu(x) + block(relu(x)).  The reference also overwrites its argument with relu(x)
-        # (nn.ReLU(True), models.py:149); inside VQVAE nothing reads that tensor again, and the
-        # fused kernels never mutate their inputs.
-        return Fn.resblock_apply(x, engine.resblock_params(self), self.training, self.compute_dtype)
+        # y = relu(x) + block(relu(x)), AND the caller's tensor is overwritten with relu(x): the reference's block opens with
+        # nn.ReLU(True) (models.py:149) and its residual add reads the mutated tensor (models.py:158; SURVEY.md 8a note 1).
+        # Inside VQVAE the fused encoder / decoder stacks never come through here (nothing reads that tensor again there);
+        # a stand-alone ResBlock keeps the reference's visible side effect.
+        y = Fn.resblock_apply(x, engine.resblock_params(self), self.training, self.compute_dtype)
+        with torch.no_grad():
+            xn = x.permute(0, 2, 3, 1)
+            if xn.is_contiguous():                   # channels_last storage: ReLU in place by the library's own kernel
+                ops.convert(xn, torch.float32, out=xn, relu=True)
+            else:
+                x.copy_(Fn.to_nchw_view(ops.convert(xn.contiguous(), torch.float32, relu=True)))
+        return y
 
 
 class _Encoder(nn.Sequential):

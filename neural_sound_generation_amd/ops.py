@@ -61,6 +61,11 @@ class Workspace:
             self._buf[key] = buf
         return buf
 
+    def current(self, device):
+        """The buffer get() hands out for `device` right now (None before first use).  Growth REPLACES it; whoever baked
+        its address into a HIP graph keeps a reference to this tensor so the address stays theirs (FusedTrainStep.capture)."""
+        return self._buf.get((device.type, device.index))
+
 
 WS = Workspace()
 
@@ -77,24 +82,40 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def end(self, name, start, flops):
+    def end(self, name, start, flops, nbytes=0.0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.records.setdefault(name, []).append((start, ev, flops))
+        self.records.setdefault(name, []).append((start, ev, flops, nbytes))
 
     def summary(self):
-        """name -> dict(launches, total_ms, avg_ms, flops_per_launch, tflops)  (call after a synchronize)"""
+        """name -> dict(launches, total_ms, avg_ms, flops_per_launch, bytes_per_launch, tflops, tbps)  (call after a synchronize)"""
         out = {}
         for name, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            fl = [f for _, _, f in recs]
-            tot_ms, tot_fl = sum(ms), float(sum(fl))
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
+            tot_ms, tot_fl, tot_b = sum(ms), float(sum(r[2] for r in recs)), float(sum(r[3] for r in recs))
             out[name] = dict(launches=len(recs), total_ms=tot_ms, avg_ms=tot_ms / len(recs),
-                             flops_per_launch=tot_fl / len(recs), tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0)
+                             flops_per_launch=tot_fl / len(recs), bytes_per_launch=tot_b / len(recs),
+                             tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0,
+                             tbps=tot_b / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0)
         return out
 
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time gather_gemm / wgrad launches
+
+
+def _es(t) -> int:
+    return t.element_size()
+
+
+def _conv_label(d: "ConvDesc", role: str) -> str:
+    """Kernel + geometry label for the census: which gather_gemm mode a forward / dgrad of this layer runs (a transposed conv's
+    forward and a stride-2 conv's data gradient are the 4-parity-class form, MODE 1; everything else is the conv gather, MODE 0)."""
+    kw = d.k_w if d.k_w > 0 else d.k
+    geom = f"{d.k}x{kw}" + (f"/s{d.stride}" if d.stride != 1 else "")
+    if role == "wgrad":
+        return f"wgrad_gemm {geom}{' transposed' if d.transposed else ''} {d.C_in}->{d.C_out}"
+    mode1 = bool(d.transposed) if role == "forward" else (not d.transposed and d.stride == 2)
+    return f"gather_gemm MODE {1 if mode1 else 0} {geom} {role} {d.C_in}->{d.C_out}"
 
 
 def _gemm_flops(d: "ConvDesc") -> float:
@@ -127,6 +148,7 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", cod
         fn = {"mfma": "nsg_vq_forward", "valu": "nsg_debug_vq_forward_valu", "bf16x3": "nsg_vq_forward_bf16x3"}[impl]
         if impl == "bf16x3":
             lp = torch.empty(N, D, dtype=torch.bfloat16, device=x2d.device) if codes_bf16 else None
+            _lib.tag("vq_forward_bf16x3 (search + gather)", 2.0 * N * K * D, 4.0 * N * D)
             _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin), _p(lp),
                       c_int32(1 if codes_bf16 == "relu" else 0), _p(ws), c_size_t(nb), _stream())
             if codes_bf16:
@@ -134,6 +156,7 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", cod
             return idx, codes, dmin
         if codes_bf16:
             raise ValueError("vq_forward: codes_bf16 needs impl='bf16x3'")
+        _lib.tag("vq_forward (fp32 exact search + gather)", 2.0 * N * K * D, 4.0 * N * D)
         _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin),
                   _p(ws), c_size_t(nb), _stream())
     elif codes_bf16:
@@ -166,6 +189,7 @@ def index_add_rows(idx, g2d, K, want_counts=False, impl="f32", out=None, counts=
         counts = torch.empty(K, dtype=torch.float32, device=g2d.device)
     nb = _lib.query("nsg_index_add_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
     ws = WS.get(nb, g2d.device)
+    _lib.tag("index_add_rows (one-hot GEMM, %s)" % impl, 2.0 * N * K * D, 4.0 * N * D + 8.0 * N)
     _lib.call("nsg_index_add_rows_bf16x2" if impl == "bf16x2" else "nsg_index_add_rows", _p(idx), _p(g2d), c_int64(N), c_int32(D),
               c_int32(K), _p(out), _p(counts), _p(ws), c_size_t(nb), _stream())
     return (out, counts) if want_counts else out
@@ -273,6 +297,7 @@ def pack_weights_batch(jobs):
         fp[i] = wf.data_ptr() if wf is not None else None
         dp[i] = wd.data_ptr() if wd is not None else None
         out.append((wf, wd))
+    _lib.tag("pack_weights_batch", 0, sum(4.0 * j[1].numel() for j in jobs) + sum((a.numel() * _es(a) if a is not None else 0) + (b.numel() * _es(b) if b is not None else 0) for a, b in out))
     _lib.call("nsg_pack_conv_weights_batch", c_int32(n), ctypes.cast(descs, c_void_p), ctypes.cast(wp, c_void_p),
               ctypes.cast(fp, c_void_p), ctypes.cast(dp, c_void_p), _stream())
     return out
@@ -292,6 +317,7 @@ def conv_forward(d: ConvDesc, x, w_fwd, bias, flags=0, out=None):
     ws, nb = _conv_ws(d, x.device)
     timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
     t0 = KERNEL_TIMER.begin() if timed else None
+    _lib.tag(_conv_label(d, "forward"), _gemm_flops(d))
     _lib.call("nsg_conv_forward", byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), c_int32(flags), _p(ws), c_size_t(nb), _stream())
     if timed:
         KERNEL_TIMER.end("gather_gemm_f32", t0, _gemm_flops(d))
@@ -310,6 +336,7 @@ def conv_forward_bnstats(d: ConvDesc, x, w_fwd, bias, flags=0, running_mean=None
     ws, nb = _conv_ws(d, x.device)
     timed = KERNEL_TIMER is not None and d.C_in > 1 and d.C_out > 1
     t0 = KERNEL_TIMER.begin() if timed else None
+    _lib.tag(_conv_label(d, "forward"), _gemm_flops(d))
     _lib.call("nsg_conv_forward_bnstats", byref(d), _p(x), _p(w_fwd), _p(bias), _p(y), c_int32(flags), c_float(eps),
               c_float(momentum), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(ws), c_size_t(nb), _stream())
     if timed:
@@ -332,9 +359,11 @@ def conv_dgrad(d: ConvDesc, dy, w_dgrad, out=None, add=None, relu_x=None):
                 _chk(t, nm, dx.dtype)
                 if t.shape != dx.shape:
                     raise _lib.NsgError(f"conv_dgrad: {nm} shape {tuple(t.shape)} does not match dx {tuple(dx.shape)}")
+        _lib.tag(_conv_label(d, "dgrad"), _gemm_flops(d))
         _lib.call("nsg_conv_dgrad_relu_add", byref(d), _p(dy), _p(w_dgrad), _p(add), _p(relu_x), _p(dx), c_int32(0), _p(ws),
                   c_size_t(nb), _stream())
     else:
+        _lib.tag(_conv_label(d, "dgrad"), _gemm_flops(d))
         _lib.call("nsg_conv_dgrad", byref(d), _p(dy), _p(w_dgrad), _p(dx), c_int32(0), _p(ws), c_size_t(nb), _stream())
     if timed:
         KERNEL_TIMER.end("gather_gemm_f32", t0, _gemm_flops(d))
@@ -348,6 +377,7 @@ def conv_wgrad(d: ConvDesc, x, dy, w_shape, flags=0, dw=None, dbias=None, want_b
     if dbias is None and want_bias:
         dbias = torch.empty(d.C_out, dtype=torch.float32, device=x.device)
     ws, nb = _conv_ws(d, x.device)
+    _lib.tag(_conv_label(d, "wgrad"), _gemm_flops(d))
     _lib.call("nsg_conv_wgrad", byref(d), _p(x), _p(dy), _p(dw), _p(dbias), c_int32(flags), _p(ws), c_size_t(nb), _stream())
     return dw, dbias
 
@@ -362,6 +392,7 @@ def bn_stats(x, C, running_mean=None, running_var=None, eps=BN_EPS, momentum=BN_
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
+    _lib.tag("bn_stats", 0, x.numel() * _es(x))
     _lib.call("nsg_bn_stats", _p(x), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), c_float(eps), c_float(momentum), _p(mean), _p(invstd),
               _p(running_mean), _p(running_var), _p(ws), c_size_t(nb), _stream())
     return mean, invstd
@@ -385,6 +416,7 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=False, residual=None, relu_resid
     C = mean.numel()
     M = x.numel() // C
     y = out if out is not None else torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    _lib.tag("bn_apply", 0, x.numel() * _es(x) * (2 if residual is not None else 1) + y.numel() * _es(y))
     _lib.call("nsg_bn_apply", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), _p(y), c_int64(M), c_int32(C),
               c_int32((1 if relu else 0) | (2 if relu_out else 0)), c_int32(1 if relu_residual else 0), c_int32(nsg_dtype(x.dtype)),
               c_int32(nsg_dtype(y.dtype)),
@@ -408,6 +440,7 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
+    _lib.tag("bn_backward (sums pass + apply pass)", 0, 5.0 * x.numel() * _es(x))
     _lib.call("nsg_bn_backward", _p(x), _p(y_relu), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(relu_beta), _p(dx), _p(dgamma), _p(dbeta),
               _p(dx_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return dx, dgamma, dbeta
@@ -434,6 +467,7 @@ def c1conv_bn_relu_forward(img, w, bias, gamma, beta, running_mean=None, running
     y = torch.empty((B, H // 2, W // 2, C), dtype=out_dtype, device=img.device)
     nb = _lib.query("nsg_c1conv_bn_workspace_bytes", c_int32(C))
     ws = WS.get(nb, img.device)
+    _lib.tag("c1conv_bn_relu_forward (fused input layer)", 2.0 * 16 * y.numel() * (2 if training else 1), 4.0 * img.numel() * (2 if training else 1) + y.numel() * _es(y))
     _lib.call("nsg_c1conv_bn_relu_forward", _p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(running_mean),
               _p(running_var), c_float(eps), c_float(momentum), c_int32(1 if training else 0), _p(y), c_int32(nsg_dtype(out_dtype)),
               c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws), c_size_t(nb), _stream())
@@ -454,6 +488,7 @@ def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None
     dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
     nb = _lib.query("nsg_c1conv_bn_workspace_bytes", c_int32(C))
     ws = WS.get(nb, dev)
+    _lib.tag("c1conv_bn_relu_backward (fused input layer)", 2.0 * 16 * dy.numel() * 3, 2.0 * (4.0 * img.numel() + dy.numel() * _es(dy)))
     _lib.call("nsg_c1conv_bn_relu_backward", _p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dy),
               c_int32(nsg_dtype(dy.dtype)), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C),
               _p(ws), c_size_t(nb), _stream())
@@ -479,6 +514,7 @@ def bn_relu_conv1x1_forward(x, mean, invstd, gamma, beta, w, bias):
     M = x.numel() // C
     y = torch.empty_like(x)
     ws, nb = _ws_1x1(M, C, x.device)
+    _lib.tag("flat_gemm 1x1 forward (bn+relu on load)", 2.0 * M * C * C, 2.0 * x.numel() * _es(x))
     _lib.call("nsg_bn_relu_conv1x1_forward", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), c_int64(M), c_int32(C),
               c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return y
@@ -495,6 +531,7 @@ def bn_relu_conv1x1_forward_bnstats(x, mean, invstd, gamma, beta, w, bias, runni
     mean_y = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd_y = torch.empty(C, dtype=torch.float32, device=x.device)
     ws, nb = _ws_1x1(M, C, x.device)
+    _lib.tag("flat_gemm 1x1 forward (bn+relu on load, stats out)", 2.0 * M * C * C, 2.0 * x.numel() * _es(x))
     _lib.call("nsg_bn_relu_conv1x1_forward_bnstats", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), c_float(eps),
               c_float(momentum), _p(mean_y), _p(invstd_y), _p(running_mean), _p(running_var), c_int64(M), c_int32(C),
               c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
@@ -508,6 +545,7 @@ def bn_relu_conv1x1_wgrad(x, mean, invstd, gamma, beta, dy, dw=None):
     M = x.numel() // C
     dw = dw if dw is not None else torch.empty((C, C, 1, 1), dtype=torch.float32, device=x.device)
     ws, nb = _ws_1x1(M, C, x.device)
+    _lib.tag("wgrad_gemm 1x1 (bn+relu on load)", 2.0 * M * C * C, 2.0 * x.numel() * _es(x))
     _lib.call("nsg_bn_relu_conv1x1_wgrad", _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(dy), _p(dw), c_int64(M), c_int32(C),
               c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return dw
@@ -522,6 +560,7 @@ def bn_backward_sums(x, dy, mean, invstd, gamma, dgamma=None, dbeta=None, relu_b
     dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
+    _lib.tag("bn_backward_sums", 0, 2.0 * x.numel() * _es(x))
     _lib.call("nsg_bn_backward_sums", _p(x), _p(None), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(relu_beta), _p(dgamma), _p(dbeta),
               c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return dgamma, dbeta
@@ -543,6 +582,7 @@ def bn_backward_conv1x1_dgrad(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh_c
         _chk(px, "prev_x", h.dtype)
         prev_dgamma = prev_dgamma if prev_dgamma is not None else torch.empty(C, dtype=torch.float32, device=h.device)
         prev_dbeta = prev_dbeta if prev_dbeta is not None else torch.empty(C, dtype=torch.float32, device=h.device)
+    _lib.tag("flat_gemm 1x1 dgrad (bn backward on load)", 2.0 * M * C * C, (5.0 if prev is not None else 4.0) * h.numel() * _es(h))
     _lib.call("nsg_bn_backward_conv1x1_dgrad", _p(h), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(w), _p(dh), _p(dx),
               _p(dh_colsum), _p(px), _p(pm), _p(pi), _p(pg), _p(pb), _p(prev_dgamma if prev is not None else None),
               _p(prev_dbeta if prev is not None else None), c_int64(M), c_int32(C), c_int32(nsg_dtype(h.dtype)), _p(ws), c_size_t(nb), _stream())
@@ -559,6 +599,7 @@ def bn_backward_apply(x, dy, mean, invstd, gamma, dgamma, dbeta, relu_beta=None,
     dx = torch.empty_like(x)
     nb = _lib.query("nsg_bn_workspace_bytes", c_int64(M), c_int32(C))
     ws = WS.get(nb, x.device)
+    _lib.tag("bn_backward_apply", 0, 3.0 * x.numel() * _es(x))
     _lib.call("nsg_bn_backward_apply", _p(x), _p(None), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(relu_beta), _p(dgamma), _p(dbeta), _p(dx),
               _p(dx_colsum), c_int64(M), c_int32(C), c_int32(nsg_dtype(x.dtype)), _p(ws), c_size_t(nb), _stream())
     return dx
@@ -579,6 +620,7 @@ def bn_relu_c1convt_forward(u, mean, invstd, gamma, beta, w, bias, tanh=True):
     y = torch.empty((B, 2 * H, 2 * W, 1), dtype=torch.float32, device=u.device)
     nb = _lib.query("nsg_bn_relu_c1convt_workspace_bytes", c_int32(B), c_int32(H), c_int32(W), c_int32(C))
     ws = WS.get(nb, u.device)
+    _lib.tag("bn_relu_c1convt_forward (fused output layer)", 2.0 * 16 * u.numel(), u.numel() * _es(u) + 4.0 * y.numel())
     _lib.call("nsg_bn_relu_c1convt_forward", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias),
               _p(y), c_int32(NSG_TANH_OUT if tanh else 0), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws), c_size_t(nb), _stream())
     return y
@@ -600,6 +642,7 @@ def bn_relu_c1convt_backward(u, mean, invstd, gamma, beta, w, dy, dw=None, dbias
     dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
     nb = _lib.query("nsg_bn_relu_c1convt_workspace_bytes", c_int32(B), c_int32(H), c_int32(W), c_int32(C))
     ws = WS.get(nb, dev)
+    _lib.tag("bn_relu_c1convt_backward (fused output layer)", 2.0 * 16 * u.numel() * 3, 3.0 * u.numel() * _es(u) + 2.0 * 4.0 * dy.numel())
     _lib.call("nsg_bn_relu_c1convt_backward", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(dy),
               _p(du), _p(du_colsum), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws),
               c_size_t(nb), _stream())
@@ -624,6 +667,7 @@ def convert(src, dtype, out=None, relu=False):
     if src.dtype == dtype and out is None and not relu:
         return src
     dst = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    _lib.tag("convert", 0, src.numel() * _es(src) + dst.numel() * _es(dst))
     _lib.call("nsg_convert", _p(src), c_int32(nsg_dtype(src.dtype)), _p(dst), c_int32(nsg_dtype(dst.dtype)), c_int64(src.numel()),
               c_int32(1 if relu else 0), _stream())
     return dst
@@ -631,6 +675,7 @@ def convert(src, dtype, out=None, relu=False):
 
 def tanh_backward(g, y, out=None):
     dx = out if out is not None else torch.empty_like(y)
+    _lib.tag("tanh_backward", 0, 12.0 * y.numel())
     _lib.call("nsg_tanh_backward", _p(g), _p(y), _p(dx), c_int64(y.numel()), _stream())
     return dx
 
@@ -669,6 +714,7 @@ def mse_padded(a, c, rows, wa, wc, grad_scale=1.0, want_grad=True):
     da = torch.empty_like(a) if want_grad else None
     nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(rows * wc))
     ws = WS.get(nb, a.device)
+    _lib.tag("mse_padded (loss + gradient)", 0, 4.0 * (a.numel() * (2 if want_grad else 1) + c.numel()))
     _lib.call("nsg_mse_padded", _p(a), _p(c), c_int64(rows), c_int32(wa), c_int32(wc), c_float(grad_scale), _p(loss), _p(da),
               _p(ws), c_size_t(nb), _stream())
     return loss, da
@@ -686,6 +732,7 @@ def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_
     dq = torch.empty_like(z) if want_dq else None
     nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(n))
     ws = WS.get(nb, z.device)
+    _lib.tag("vq_losses", 0, 4.0 * n * 2 + (dz.numel() * _es(dz) * (2 if dz_add is not None else 1) if dz is not None else 0) + (4.0 * n if dq is not None else 0))
     _lib.call("nsg_vq_losses", _p(z), _p(q), c_int64(n), c_float(dz_scale), c_float(dq_scale), _p(dz_add), _p(loss), _p(dz),
               _p(dq), c_int32(nsg_dtype(grad_dtype)), _p(ws), c_size_t(nb), _stream())
     return loss, dz, dq
@@ -701,12 +748,14 @@ def vq_losses_indexed(z2d, codebook, idx, dz_scale=1.0, dz_add=None, want_dz=Tru
     dz = torch.empty(z2d.shape, dtype=grad_dtype, device=z2d.device) if want_dz else None
     nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(N * D))
     ws = WS.get(nb, z2d.device)
+    _lib.tag("vq_losses_indexed", 0, 4.0 * N * D + 8.0 * N + (dz.numel() * _es(dz) * (2 if dz_add is not None else 1) if dz is not None else 0))
     _lib.call("nsg_vq_losses_indexed", _p(z2d), _p(codebook), _p(idx), c_int64(N), c_int32(D), c_int32(codebook.shape[0]), c_float(dz_scale),
               _p(dz_add), _p(loss), _p(dz), c_int32(nsg_dtype(grad_dtype)), _p(ws), c_size_t(nb), _stream())
     return loss, dz
 
 
 def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _lib.tag("adam_step", 0, 28.0 * p.numel())
     _lib.call("nsg_adam_step", _p(p), _p(g), _p(m), _p(v), c_int64(p.numel()), c_float(lr), c_float(beta1), c_float(beta2),
               c_float(eps), c_int32(step), c_float(grad_scale), _stream())
 

@@ -143,9 +143,17 @@ class FusedTrainStep:
         self._static_c = c.clone()
         self._static_g = g.clone() if g is not None else None
         torch.cuda.synchronize()
+        # The captured launches carry the scratch buffer's ADDRESS (ops.WS).  A later call that needs more scratch (a longer
+        # T from the bucketed sampler, eval_losses, the prior, the audio export) makes the workspace allocate a new buffer
+        # and drop the old one; this graph keeps the old one alive, so its replays never touch memory someone else owns.
+        ws = ops.WS.current(c.device)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_losses = self.forward_backward(self._static_c, self._static_g)
+        if ops.WS.current(c.device) is not ws:
+            self._graph = None
+            raise RuntimeError("FusedTrainStep.capture: the workspace grew during capture (warm-up steps must see the captured shapes)")
+        self._graph_ws = ws
         return self
 
     def _replay(self, c, g):
