@@ -148,7 +148,7 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", cod
         fn = {"mfma": "nsg_vq_forward", "valu": "nsg_debug_vq_forward_valu", "bf16x3": "nsg_vq_forward_bf16x3"}[impl]
         if impl == "bf16x3":
             lp = torch.empty(N, D, dtype=torch.bfloat16, device=x2d.device) if codes_bf16 else None
-            _lib.tag("vq_forward_bf16x3 (search + gather)", 2.0 * N * K * D, 4.0 * N * D)
+            _lib.tag("vq_forward_bf16x3 (search + gather)", 2.0 * N * K * D)
             _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin), _p(lp),
                       c_int32(1 if codes_bf16 == "relu" else 0), _p(ws), c_size_t(nb), _stream())
             if codes_bf16:
@@ -156,7 +156,7 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", cod
             return idx, codes, dmin
         if codes_bf16:
             raise ValueError("vq_forward: codes_bf16 needs impl='bf16x3'")
-        _lib.tag("vq_forward (fp32 exact search + gather)", 2.0 * N * K * D, 4.0 * N * D)
+        _lib.tag("vq_forward (fp32 exact search + gather)", 2.0 * N * K * D)
         _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin),
                   _p(ws), c_size_t(nb), _stream())
     elif codes_bf16:

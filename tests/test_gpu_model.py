@@ -213,7 +213,8 @@ def test_reference_train_step_statement_for_statement(golden_dir, si, flat_adam)
     loss_commit = F.mse_loss(z_e_x, z_q_x.detach())
     loss = loss_recons + loss_vq + beta * loss_commit
     loss.backward()
-    named = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+    named = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}      # (observation, not a statement
+    idx = model.codebook(z_e_x.detach()).cpu().numpy()                                           #  of the reference's)
     optimizer.step()
     train_loss = loss_recons.item() + loss_vq.item()
     # ---- against the reference's own numbers for this batch ----
@@ -223,7 +224,6 @@ def test_reference_train_step_statement_for_statement(golden_dir, si, flat_adam)
     assert rel(train_loss, float(g[tag + "losses"][0] + g[tag + "losses"][1])) < LOSS_RTOL
     np.testing.assert_allclose(x_tilde.detach().cpu().numpy(), g[tag + "x_tilde"], rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(z_e_x.detach().cpu().numpy(), g[tag + "z_e"], rtol=1e-4, atol=5e-6)
-    idx = model.codebook(z_e_x.detach()).cpu().numpy()
     flips = index_flips_are_near_ties(idx, g[tag + "idx"], g[tag + "z_e"], g["sd0.codebook.embedding.weight"])
     assert flips <= max(1, idx.size // 500), f"{flips} index flips"
     if flips == 0:
@@ -434,12 +434,25 @@ def test_large_codebook_step_against_oracle():
     ze_rows = rec["z_e"].permute(0, 2, 3, 1).reshape(-1, dim).contiguous()
     idx_same, _, _ = ops.vq_forward(ze_rows.to(DEV), st0["codebook.embedding.weight"].to(DEV), want_codes=False)
     assert np.array_equal(idx_same.cpu().numpy(), idx_ref.reshape(-1))
-    # decoder-side gradients (not behind the flipped rows' ill-conditioned encoder path) agree with the oracle's
+    # gradients, judged against an fp64 evaluation of the oracle.  Every BatchNorm backward on the way amplifies a relative
+    # error ~5x (it cancels most of its input gradient), and the seed is a handful of ReLU-boundary sign differences between
+    # ANY fp32 evaluation and fp64 (pre-activations differ in the last ulps: sequential-k fp32 MFMA chains vs oneDNN's
+    # blocking; scripts/grad_accuracy_table.py, scripts/op_accuracy_probe.py: every operator alone is good to 1e-7).  At
+    # the headline shape (D=128, two clips) the CPU oracle and the GPU both land at 1-3e-3 on the deepest tensors; here,
+    # one clip, the CPU oracle happens to land at 1e-6, so "a small multiple of the CPU's distance" has a 5e-3 floor.
+    rec64 = O.forward_backward(O.clone_state({k: (v.double() if v.is_floating_point() else v) for k, v in st0.items()}), c.double())
+    exact = flips == 0 and bool((rec64["idx"] == rec["idx"]).all())
     for k, p in model.named_parameters():
-        if k.startswith("decoder.") and not is_noise_bias(k):
-            want = rec["grads"][k].double()
-            err = (p.grad.double().cpu() - want).norm().item() / max(want.norm().item(), 1e-12)
-            assert err < (5e-3 if flips else 2e-4), f"{k}: relative L2 distance {err:.3e} to the oracle's gradient"
+        if is_noise_bias(k):
+            continue
+        truth = rec64["grads"][k]
+        tn = max(truth.norm().item(), 1e-12)
+        err_gpu = (p.grad.double().cpu() - truth).norm().item() / tn
+        err_cpu = (rec["grads"][k].double() - truth).norm().item() / tn
+        if exact:
+            assert err_gpu <= max(4.0 * err_cpu + 1e-4, 5e-3), f"{k}: GPU {err_gpu:.2e} vs CPU-fp32 {err_cpu:.2e} (relative L2 distance to the fp64 result)"
+        elif k.startswith("decoder."):
+            assert err_gpu < 2e-2, f"{k}: relative L2 distance {err_gpu:.3e} to the fp64 gradient"
     g1 = step.opt.flat_grad.clone()
     model2 = M.VQVAE(1, dim, z_dim)
     model2.load_state_dict(st0)
