@@ -635,6 +635,11 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p_in, hipStream_t s)
     p.div_rhw = nsg_fastdiv((uint32_t)p.RH * (uint32_t)p.RW);
     if (p.CI % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "gather_gemm: C_in=%d not a multiple of %d", p.CI, epv);
     if (!nsg_aligned16(p.in) || !nsg_aligned16(p.w)) return nsg_fail(NSG_E_INVALID, "gather_gemm: operands must be 16-byte aligned");
+    {
+        bool handled = false;
+        const int rc = nsg_launch_patch_gemm(p, s, &handled);
+        if (handled || rc != NSG_OK) return rc;
+    }
     if (p.in_dtype == NSG_F32 && p.out_dtype == NSG_F32) return launch_typed<float, float>(p, s);
     if (p.in_dtype == NSG_BF16 && p.out_dtype == NSG_BF16) return launch_typed<bf16_t, bf16_t>(p, s);
     if (p.in_dtype == NSG_BF16 && p.out_dtype == NSG_F32) return launch_typed<bf16_t, float>(p, s);

@@ -1,0 +1,417 @@
+// Implicit-GEMM convolution on the bf16 matrix cores with the INPUT PATCH staged once in LDS ("LDS-staged input tiles",
+// BASELINE.json north_star) -- the bf16 form of nn.Conv2d / nn.ConvTranspose2d forward and of both data gradients
+// (reference call sites: src/models.py:150,168,179 and their autograd).  gemm_gather.hip's kernel stages the gathered A
+// operand once PER TAP (9x for a 3x3, 16x for a 4x4: the VGPR -> LDS path and 1.56x the algorithmic HBM traffic were its
+// measured limits); here:
+//
+//   * a workgroup owns a 2-D tile of 4 rows x 32 columns of the output grid (128 pixels) x 128 output channels;
+//   * per 64-channel chunk it stages the tile's input patch INCLUDING THE HALO once (6 x 34 pixels for a 3x3; 5 x 33 per
+//     parity plane / parity class for the stride-2 forms, whose 16 taps are four 2x2 convolutions) -- global -> registers ->
+//     LDS, double-buffered, loads issued a whole job ahead of the ds_write (a "job" = one patch + the taps that read it);
+//   * every tap is then only a different LDS ROW ADDRESS: lane x of tile row y reads patch slot (y*PW + x) + delta(tap).
+//     Slots are padded to 144 bytes (9 x 16): 16 consecutive slots land on 16 different 16-byte bank groups, so the
+//     ds_read_b128 fragment reads are conflict-free with plain linear addressing (one v_add per tile row per tap);
+//   * the weights never touch LDS: wave w owns output channels 32w..32w+31 for all 128 pixels, so its B-operand fragments
+//     are 16-byte loads straight from the packed [tap][co][ci] image into registers (L2-resident, 288 KB for a 3x3),
+//     double-buffered one tap ahead.  No barrier inside a job: one workgroup barrier per job (every 64-144 MFMAs per wave);
+//   * v_mfma_f32_32x32x16_bf16 with the operands swapped (weights as A, pixels as B): an accumulator register group holds 4
+//     consecutive channels of one pixel; the epilogue stages one tile row at a time (fp32) through the patch buffer that has
+//     just been retired and stores 16-byte row-contiguous pieces with bias / ReLU / the ResBlock's skip-gradient add and
+//     ReLU mask applied -- the same arithmetic, in the same order, as gemm_gather.hip's epilogue;
+//   * workgroups walk tiles with a grid stride: patch and weight prefetch run across tile boundaries.
+//
+// MODE 1 (transposed 4/2/1 forward = data gradient of a 4/2/1 conv): the four output parity classes of one 4 x 32 block of
+// the low-resolution grid are four consecutive "classes" of one workgroup (4 x 128 output pixels), each with its own 2x2
+// taps, accumulators flushed per class.
+#include "nsg_common.h"
+#include <type_traits>
+
+namespace {
+
+int g_patch_gemm = 1;        // nsg_debug_set_patch_gemm: 0 sends everything back to gemm_gather.hip's kernel (A/B runs)
+int g_patch_grid_cap = 0;    // nsg_debug_set_patch_grid: > 0 caps the grid (workgroups then walk several tiles); 0 = one tile each
+
+constexpr int PG_MAX_JOBS = 16;
+constexpr int PG_MAX_TAPS = 64;
+constexpr int SLOT_BYTES = 144;     // 128 bytes of a pixel's 64-channel chunk + 16 bytes of padding (bank spread)
+
+struct PatchJob {
+    int c0_bytes;       // byte offset of the channel chunk inside a pixel
+    short jy, jx;       // input pixel of patch slot (yy, xx) = (tile_y0 * sy + jy + yy * sy, tile_x0 * sx + jx + xx * sx)
+    short oy, ox;       // MODE 1: parity class (py, px) of the outputs this job contributes to
+    int flush;          // 1: the accumulators are complete after this job (store them)
+};
+struct PatchTap {
+    int delta_bytes;        // LDS byte offset of the tap inside the patch (slot delta * SLOT_BYTES)
+    unsigned woff_bytes;    // byte offset of (weight tap, chunk) in the packed [tap][co][ci] image
+};
+
+struct PatchGemmParams {
+    const bf16_t *in;
+    const bf16_t *w;
+    const float *bias;
+    bf16_t *out;
+    const bf16_t *epi_add;
+    const bf16_t *epi_mask;
+    int B, IH, IW, CI, OH, OW, CO;
+    int tiles_y, tiles_x, ntiles;
+    FastDiv div_tx, div_tyx;
+    int njobs, ntaps;
+    int sy, sx;             // input step per patch slot (1, or 2 for the parity planes of a stride-2 conv)
+    int os;                 // output step (1, or 2 for the transposed form)
+    int flags;
+    unsigned in_bytes, w_bytes;
+    PatchJob jobs[PG_MAX_JOBS];
+    PatchTap taps[PG_MAX_TAPS];
+};
+
+// PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4)
+template <int PH, int PW, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
+{
+    constexpr int NSLOT = PH * PW;
+    constexpr int NPIECE = NSLOT * 8;                       // 16-byte pieces of a patch (64 channels = 8 pieces per slot)
+    constexpr int NP = (NPIECE + 255) / 256;                // pieces per thread
+    constexpr int BUF_BYTES = ((NSLOT * SLOT_BYTES + 255) / 256) * 256;
+    constexpr int CPITCH = 132;                             // epilogue staging pitch (floats): [32 pixels][128 channels + 4]
+    static_assert(32 * CPITCH * 4 <= BUF_BYTES, "a tile row of the output must fit a retired patch buffer");
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][BUF_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * 128;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- this thread's patch pieces: piece i = tid + 256 r -> slot i >> 3 (yy, xx), 16-byte piece i & 7 ----
+    int pc_yx[NP];                           // (yy << 8) | xx; an invalid slot (the ragged end of the last pass) has yy far outside
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        const int slot = (tid >> 3) + 32 * r;
+        pc_yx[r] = slot < NSLOT ? ((slot / PW) << 8) | (slot % PW) : (0x4000 << 8);
+    }
+    const unsigned pc_lds0 = (unsigned)(tid >> 3) * SLOT_BYTES + (tid & 7) * 16;     // piece r sits 32 slots further per r
+    const int piece_b = (tid & 7) * 16;                      // (256 r is a multiple of 8: the piece index does not depend on r)
+
+    // ---- fragment addressing ----
+    // A operand of the MFMA = weights: lane (r = x31, h) holds w[co = n0 + 32 wave + r][ci = c0 + 16 kk + 8 h .. + 7]
+    const unsigned wlane = (unsigned)(((n0 + 32 * wave + x31) * p.CI + 8 * h) * 2);
+    // B operand = pixels: lane (x31, h) of tile row y reads slot (y PW + x31) + delta, bytes 32 kk + 16 h
+    unsigned arow[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) arow[y] = (unsigned)((y * PW + x31) * SLOT_BYTES + 16 * h);
+
+    // epilogue: this thread's 8-channel group and its bias
+    const int cg = tid & 15;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
+    const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
+
+    // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
+    // would share lgkmcnt with the fragment reads and drain them.
+    const int tab_delta = p.taps[lane].delta_bytes;
+    const int tab_woff = (int)p.taps[lane].woff_bytes;
+    static_assert(PG_MAX_TAPS <= 64, "one lane per table entry");
+    auto tap_delta = [&](int q) { return __builtin_amdgcn_readlane(tab_delta, q); };
+    auto tap_woff = [&](int q) { return __builtin_amdgcn_readlane(tab_woff, q); };
+
+    v16f acc[4];
+    v4f breg[2][4];          // weight fragments of two taps (4 k-steps of 16 channels each)
+    v4f preg[NP];            // the patch in flight: global -> registers a job ahead of its ds_write
+
+    // ---- job stream: (tile, job) for this workgroup, tiles bid, bid + grid, ... ----
+    const int G = gridDim.x;
+    struct Cursor { int tile, job; };
+    auto advance = [&](Cursor &c) {
+        if (++c.job == p.njobs) { c.job = 0; c.tile += G; }
+    };
+    auto tile_origin = [&](int tile, int &b, int &ty, int &tx) {
+        b = nsg_div(tile, p.div_tyx);
+        const int rem = tile - b * (p.tiles_y * p.tiles_x);
+        ty = nsg_div(rem, p.div_tx);
+        tx = rem - ty * p.tiles_x;
+    };
+    auto load_patch = [&](const Cursor &c) {
+        if (c.tile >= p.ntiles) return;                      // past the end of the stream: nothing to fetch (never stored either)
+        int b, ty, tx;
+        tile_origin(c.tile, b, ty, tx);
+        const PatchJob jb = p.jobs[c.job];
+        const int iy0 = ty * 4 * p.sy + jb.jy, ix0 = tx * 32 * p.sx + jb.jx;
+        const unsigned cb = (unsigned)(jb.c0_bytes + piece_b);
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int iy = iy0 + (pc_yx[r] >> 8) * p.sy, ix = ix0 + (pc_yx[r] & 255) * p.sx;
+            const bool ok = (iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW);
+            const unsigned off = ok ? (unsigned)(((b * p.IH + iy) * p.IW + ix) * p.CI) * 2u + cb : OOB;
+            preg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
+        }
+    };
+    auto store_patch = [&](int buf) {
+        char *base = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int r = 0; r < NP; ++r)
+            if (NPIECE % 256 == 0 || r + 1 < NP || tid + 256 * r < NPIECE) *reinterpret_cast<v4f *>(base + pc_lds0 + r * 32 * SLOT_BYTES) = preg[r];
+    };
+    auto load_b = [&](v4f (&bq)[4], int q) {
+        const int so = tap_woff(q);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 32 * kk), (int)so, 0));
+    };
+    v4f afr[4];              // pixel fragments of one k-step (4 tile rows): each is re-read for the next k-step right after its MFMA
+    auto read_a1 = [&](int y, int buf, int q, int kk) {
+        afr[y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 32 * kk + arow[y]);
+    };
+    // One tap = 4 k-steps of 16 channels.  On entry afr holds k-step 0 of tap q; on exit k-step 0 of tap qn.  At the end of
+    // a job qn = q: the next patch is not visible before the job-boundary barrier, so the read is a dummy (branch-free) and
+    // run_job reads the real fragments after the barrier.
+    auto compute_tap = [&](const v4f (&bq)[4], v4f (&bnext)[4], int buf, int q, int qn, int qb) {
+        load_b(bnext, qb);                                  // the weight fragments of the tap after this one: a whole tap to land
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);  // (pinned here: left alone, the scheduler sinks them to their first use)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[y]), acc[y], 0, 0, 0);
+                if (kk < 3) read_a1(y, buf, q, kk + 1);
+                else read_a1(y, buf, qn, 0);
+            }
+            // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next three MFMAs)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+    };
+
+    // ---- epilogue of one output class of one tile: four passes (one tile row each) through the retired patch buffer ----
+    auto flush = [&](int tile, const PatchJob &jb, int buf) {
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+        float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
+        // this thread's 8 output pieces: tile row y, pixel (tid >> 4) + 16 e2, channels 8 cg .. + 7
+        int off[4][2];
+        v4f addv[4][2], maskv[4][2];
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int oy = (ty * 4 + y) * p.os + jb.oy;
+                const int ox = (tx * 32 + (tid >> 4) + 16 * e2) * p.os + jb.ox;
+                off[y][e2] = (oy < p.OH && ox < p.OW) ? ((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + 8 * cg : -1;   // (< 2^31: the launcher checks)
+            }
+        if (p.epi_add) {        // the skip-path gradient (the ResBlock's residual add, backward): all 8 pieces in flight at once
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) addv[y][e2] = *reinterpret_cast<const v4f *>(p.epi_add + (off[y][e2] < 0 ? 0 : off[y][e2]));
+        }
+        if (p.epi_mask) {       // the ReLU whose OUTPUT is epi_mask
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) maskv[y][e2] = *reinterpret_cast<const v4f *>(p.epi_mask + (off[y][e2] < 0 ? 0 : off[y][e2]));
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            // this wave's 32 pixels x 32 channels of tile row y: register group g of lane (x, h) = channels 32 w + 8 g + 4 h .. + 3
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<v4f *>(Cs + x31 * CPITCH + 32 * wave + 8 * g + 4 * h) =
+                    v4f{acc[y][4 * g], acc[y][4 * g + 1], acc[y][4 * g + 2], acc[y][4 * g + 3]};
+            __syncthreads();
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                if (off[y][e2] < 0) continue;
+                const int px = (tid >> 4) + 16 * e2;
+                const v4f t0 = *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg);
+                const v4f t1 = *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg + 4);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];
+                if (p.epi_add) {
+                    float t[8];
+                    Elem<bf16_t>::unpack16(addv[y][e2], t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t[e];
+                }
+                if (p.epi_mask) {
+                    float t[8];
+                    Elem<bf16_t>::unpack16(maskv[y][e2], t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+                }
+                Elem<bf16_t>::store16(p.out + off[y][e2], v);
+            }
+            __syncthreads();        // the staging rows are rewritten by the next pass (or by the next patch)
+        }
+    };
+
+    // ---- the stream ----
+    // Workgroups are dealt round-robin over the 8 XCDs (observed, speed only): give each XCD a contiguous run of tiles so that
+    // the halo rows a tile shares with its vertical neighbours are hits in that XCD's L2.  Bijective for any grid size.
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, qq = G >> 3, rr = G & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    }
+    Cursor cur = {bid, 0};                  // job being computed
+    Cursor pre = cur;                       // job whose patch is being fetched
+    if (cur.tile >= p.ntiles) return;
+    load_patch(pre);
+    store_patch(0);
+    advance(pre);
+    load_patch(pre);                        // job 1 -> registers
+    load_b(breg[0], 0);
+    zero_acc();
+    __syncthreads();
+    int buf = 0;
+    int par = 0;                            // which breg holds the current tap
+    // One job: NT taps from patch buffer `buf`; weight fragments of tap q + 1 (wrapping: the weights do not depend on the tile)
+    // are fetched while tap q runs.  P = parity of the job's first tap in the breg pair (NT odd flips it every job).
+    auto run_job = [&](auto PAR, int qbase, int qnext_base) {
+        constexpr int P = decltype(PAR)::value;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) read_a1(y, buf, qbase, 0);
+#pragma unroll 1
+        for (int t = 0; t + 1 < NT; t += 2) {       // taps in pairs: the two breg halves swap roles inside the body
+            compute_tap(breg[P], breg[P ^ 1], buf, qbase + t, qbase + t + 1, qbase + t + 1);
+            const int q2 = t + 2 < NT ? qbase + t + 2 : qnext_base;
+            compute_tap(breg[P ^ 1], breg[P], buf, qbase + t + 1, t + 2 < NT ? qbase + t + 2 : qbase + t + 1, q2);
+        }
+        if constexpr (NT & 1) compute_tap(breg[P], breg[P ^ 1], buf, qbase + NT - 1, qbase + NT - 1, qnext_base);
+    };
+    while (cur.tile < p.ntiles) {
+        const PatchJob jb = p.jobs[cur.job];
+        const int qbase = cur.job * NT;
+        const int qnext = (cur.job + 1 == p.njobs ? 0 : cur.job + 1) * NT;
+        if (par) run_job(std::integral_constant<int, 1>{}, qbase, qnext);
+        else     run_job(std::integral_constant<int, 0>{}, qbase, qnext);
+        par = (par + NT) & 1;
+        // job boundary: the next job's patch (in registers since the start of this job) goes to the other buffer
+        store_patch(buf ^ 1);
+        __syncthreads();                    // every wave is done with `buf`; the next patch is visible
+        advance(pre);
+        load_patch(pre);                    // two jobs ahead, lands during the next job
+        if (jb.flush) {
+            flush(cur.tile, jb, buf);
+            zero_acc();
+        }
+        advance(cur);
+        buf ^= 1;
+    }
+}
+
+template <int PH, int PW, int NT>
+int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
+{
+    constexpr int NSLOT = PH * PW;
+    constexpr size_t BUF_BYTES = ((NSLOT * SLOT_BYTES + 255) / 256) * 256;
+    const size_t lds = 2 * BUF_BYTES;
+    static LdsOptIn once;
+    if (lds > 65536) {
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT>)}, lds, "patch_gemm");
+        if (rc != NSG_OK) return rc;
+    }
+    // two workgroups per CU resident; more tiles than that are walked with a grid stride
+    int gx = p.ntiles;
+    const int cap = g_patch_grid_cap > 0 ? g_patch_grid_cap : 0;
+    if (cap > 0 && gx > cap) gx = cap;
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    return nsg_check_launch("patch_gemm");
+}
+
+}  // namespace
+
+extern "C" NSG_API void nsg_debug_set_patch_gemm(int on) { g_patch_gemm = on; }
+extern "C" NSG_API void nsg_debug_set_patch_grid(int cap) { g_patch_grid_cap = cap; }
+
+// Runs the launch on the patch-staged kernel when its shape is one this file implements; *handled says whether it did.
+int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handled)
+{
+    *handled = false;
+    if (!g_patch_gemm) return NSG_OK;
+    if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return NSG_OK;
+    if ((g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) || g.stats || g.stamps) return NSG_OK;
+    if (g.CI % 64 != 0 || g.CO % 128 != 0) return NSG_OK;
+    const int chunks = g.CI / 64;
+    int kind;    // 0: 3x3 stride 1, 1: 4x4 stride 2 pad 1, 2: transposed 4/2/1
+    if (g.mode == 1) kind = 2;
+    else if (g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad >= 0 && g.pad <= 2 && g.pad_w >= 0 && g.pad_w <= 2) kind = 0;
+    else if (g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 1 && g.pad_w == 1) kind = 1;
+    else return NSG_OK;
+    const int njobs = kind == 0 ? chunks : 4 * chunks;
+    const int ntaps = kind == 0 ? 9 : 4;
+    if (njobs > PG_MAX_JOBS || njobs * ntaps > PG_MAX_TAPS) return NSG_OK;
+
+    PatchGemmParams p = {};
+    p.in = reinterpret_cast<const bf16_t *>(g.in);
+    p.w = reinterpret_cast<const bf16_t *>(g.w);
+    p.bias = g.bias;
+    p.out = reinterpret_cast<bf16_t *>(g.out);
+    p.epi_add = reinterpret_cast<const bf16_t *>(g.epi_add);
+    p.epi_mask = reinterpret_cast<const bf16_t *>(g.epi_mask);
+    p.B = g.B; p.IH = g.IH; p.IW = g.IW; p.CI = g.CI; p.OH = g.OH; p.OW = g.OW; p.CO = g.CO;
+    p.tiles_y = (int)nsg_cdiv(g.RH, 4);
+    p.tiles_x = (int)nsg_cdiv(g.RW, 32);
+    const int64_t nt = (int64_t)g.B * p.tiles_y * p.tiles_x;
+    if (nt > 0x3fffffff) return NSG_OK;
+    p.ntiles = (int)nt;
+    p.div_tx = nsg_fastdiv((uint32_t)p.tiles_x);
+    p.div_tyx = nsg_fastdiv((uint32_t)p.tiles_y * (uint32_t)p.tiles_x);
+    p.njobs = njobs; p.ntaps = ntaps;
+    p.sy = p.sx = kind == 1 ? 2 : 1;
+    p.os = kind == 2 ? 2 : 1;
+    p.flags = g.flags;
+    p.in_bytes = g.in_bytes; p.w_bytes = g.w_bytes;
+    const int64_t tapstride = (int64_t)g.CO * g.CI;     // elements per weight tap
+    int j = 0;
+    if (kind == 0) {
+        for (int c = 0; c < chunks; ++c, ++j) {
+            p.jobs[j] = PatchJob{c * 128, (short)-g.pad, (short)-g.pad_w, 0, 0, c + 1 == chunks};
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw)
+                    p.taps[j * 9 + kh * 3 + kw] = PatchTap{(kh * 34 + kw) * SLOT_BYTES, (unsigned)(((kh * 3 + kw) * tapstride + c * 64) * 2)};
+        }
+    } else if (kind == 1) {
+        for (int c = 0; c < chunks; ++c)
+            for (int pl = 0; pl < 4; ++pl, ++j) {
+                const int ph = pl >> 1, pw = pl & 1;
+                p.jobs[j] = PatchJob{c * 128, (short)(ph - 1), (short)(pw - 1), 0, 0, j + 1 == njobs};
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        p.taps[j * 4 + a * 2 + b] = PatchTap{(a * 33 + b) * SLOT_BYTES,
+                                                           (unsigned)((((2 * a + ph) * 4 + (2 * b + pw)) * tapstride + c * 64) * 2)};
+            }
+    } else {
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            for (int c = 0; c < chunks; ++c, ++j) {
+                p.jobs[j] = PatchJob{c * 128, (short)(py - 1), (short)(px - 1), (short)py, (short)px, c + 1 == chunks};
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                        p.taps[j * 4 + a * 2 + b] = PatchTap{((1 - a) * 33 + (1 - b)) * SLOT_BYTES,
+                                                           (unsigned)(((((1 - py) + 2 * a) * 4 + (1 - px) + 2 * b) * tapstride + c * 64) * 2)};
+            }
+        }
+    }
+    *handled = true;
+    const int ntn = g.CO / 128;
+    if (kind == 0) return launch_patch<6, 34, 9>(p, ntn, s);
+    return launch_patch<5, 33, 4>(p, ntn, s);
+}

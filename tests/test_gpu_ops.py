@@ -433,6 +433,73 @@ def test_conv_bf16_mode(case):
     _close(dbg.cpu(), gb, tol=1e-4, what="bias grad")
 
 
+PATCH_CASES = [
+    # (B, IH, IW, C_in, C_out, k, stride, transposed): the shapes gemm_patch.hip implements (bf16, C_in % 64 == 0, C_out % 128 == 0)
+    (2, 20, 64, 128, 128, 3, 1, False),     # the ResBlock 3x3: 5 x 2 tiles per clip
+    (3, 9, 45, 64, 128, 3, 1, False),       # ragged in both directions, one channel chunk
+    (1, 4, 32, 256, 256, 3, 1, False),      # exactly one tile, four chunks, two column tiles
+    (2, 40, 128, 128, 128, 4, 2, False),    # encoder.3: parity planes
+    (2, 22, 30, 128, 128, 4, 2, False),     # odd output extents (11 x 15)
+    (2, 11, 15, 64, 128, 4, 2, False),      # odd INPUT extents (the T = 31 path)
+    (2, 20, 64, 128, 128, 4, 2, True),      # decoder.3: four parity classes per tile
+    (3, 6, 7, 64, 128, 4, 2, True),         # ragged, small
+    (1, 5, 33, 256, 256, 4, 2, True),       # four chunks x four classes = 16 jobs
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=str)
+def test_patch_staged_conv_kernel(case):
+    """gemm_patch.hip (input patch + halo staged once in LDS, weights straight to registers) against (a) fp32 ATen on the same
+    bf16-rounded operands and (b) gemm_gather.hip's kernel on the same tensors -- same products, different summation order,
+    so outputs agree to the rounding of the bf16 store.  Forward with bias (+ ReLU for the consumer) and the data gradient
+    with the fused skip-gradient add and ReLU mask; every launch twice (bitwise reproducible)."""
+    from neural_sound_generation_amd import _lib
+    B, IH, IW, Ci, Co, k, s, tr = case
+    p = 1
+    g = torch.Generator().manual_seed(sum(case[:7]) + 17 * int(tr))
+    bf = torch.bfloat16
+    x = torch.randn(B, Ci, IH, IW, generator=g).to(bf).float()
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = (torch.randn(*wshape, generator=g) * 0.05)
+    wq = w.to(bf).float()
+    b = torch.randn(Co, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True)
+    y = F.conv_transpose2d(xr, wq, b, stride=s, padding=p) if tr else F.conv2d(xr, wq, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).to(bf).float()
+    gx, = torch.autograd.grad(y, [xr], dy)
+    d = ops.conv_desc(B, IH, IW, Ci, Co, k, s, p, transposed=tr, dtype=bf)
+    wf, wd = ops.pack_weights(d, gpu(w))
+    xg = gpu(nhwc(x)).to(bf)
+    dyg = gpu(nhwc(dy)).to(bf)
+    skip = torch.randn(B, IH, IW, Ci, generator=g).to(bf).to(DEV)
+    rx = torch.relu(torch.randn(B, IH, IW, Ci, generator=g)).to(bf).to(DEV)
+    lib = _lib.load()
+
+    def run():
+        return (ops.conv_forward(d, xg, wf, gpu(b)), ops.conv_forward(d, xg, wf, gpu(b), flags=ops.NSG_RELU_OUT),
+                ops.conv_dgrad(d, dyg, wd), ops.conv_dgrad(d, dyg, wd, add=skip, relu_x=rx))
+    new = run()
+    again = run()
+    lib.nsg_debug_set_patch_gemm(0)
+    try:
+        old = run()
+    finally:
+        lib.nsg_debug_set_patch_gemm(1)
+    for a, c in zip(new, again):
+        assert torch.equal(a, c), "the patch-staged kernel must be bitwise reproducible"
+    _close(nchw(new[0].float().cpu()), y.detach(), tol=1e-2, what="forward")
+    _close(nchw(new[1].float().cpu()), torch.relu(y.detach()), tol=1e-2, what="forward + ReLU")
+    _close(nchw(new[2].float().cpu()), gx, tol=1e-2, what="dgrad")
+    want = (gx + nchw(skip.float().cpu())) * (nchw(rx.float().cpu()) > 0)
+    _close(nchw(new[3].float().cpu()), want, tol=1e-2, what="dgrad + add + mask")
+    for a, c, what in zip(new, old, ("forward", "forward + ReLU", "dgrad", "dgrad + add + mask")):
+        a, c = a.float(), c.float()
+        scale = float(c.abs().max())
+        # one bf16 ulp at the value's own magnitude (2^-8 relative) plus the fp32 accumulation-order noise
+        assert bool(((a - c).abs() <= c.abs() * 2.0 ** -7 + 1e-5 * scale).all()), f"{what}: differs from gemm_gather beyond a bf16 ulp"
+        assert float((a != c).float().mean()) < 0.05, f"{what}: more than 5 % of the outputs round differently"
+
+
 def test_conv_rejects_unsupported_geometry():
     from neural_sound_generation_amd._lib import NsgError
     d = ops.conv_desc(1, 8, 8, 6, 8, 3, 1, 1)  # C_in not a multiple of 4
