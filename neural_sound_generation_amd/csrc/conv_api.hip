@@ -37,10 +37,13 @@ int nsg_launch_c1_stencil_wgrad(const float *img, const void *t, int t_dtype, in
 namespace {
 
 // One weight re-pack:  dst[(t*NN + n)*CC + c] = src[n*sn + c*sc + (flip ? T-1-t : t)]  (dst fp32 or bf16)
+// frag (bf16 images with NN % 128 == 0 and CC % 64 == 0 only): a SECOND image behind the first (T*NN*CC elements further) in
+// the order gemm_patch.hip's waves load their MFMA operand fragments -- [t][c / 64][n / 32][(c % 64) / 16][lane][8] with
+// lane = n % 32 + 32 * ((c % 16) / 8): one wave-wide 16-byte load = 1 KiB contiguous (nsg_frag_image_index).
 struct PackJob {
     const float *src;
     void *dst;
-    int T, NN, CC, sn, sc, flip, bf16;
+    int T, NN, CC, sn, sc, flip, bf16, frag;
 };
 constexpr int PACK_MAX_JOBS = 32;
 struct PackJobs {
@@ -56,8 +59,15 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
         const int n = (int)((i / j.CC) % j.NN);
         const int t = (int)(i / ((int64_t)j.CC * j.NN));
         const float v = j.src[(size_t)n * j.sn + (size_t)c * j.sc + (j.flip ? j.T - 1 - t : t)];
-        if (j.bf16) reinterpret_cast<bf16_t *>(j.dst)[i] = nsg_f2bf(v);
-        else        reinterpret_cast<float *>(j.dst)[i] = v;
+        if (j.bf16) {
+            reinterpret_cast<bf16_t *>(j.dst)[i] = nsg_f2bf(v);
+            if (j.frag) {
+                const int64_t fi = ((((int64_t)(t * (j.CC >> 6) + (c >> 6)) * (j.NN >> 5) + (n >> 5)) * 4 + ((c & 63) >> 4)) * 64 + (n & 31) + 32 * ((c & 15) >> 3)) * 8 + (c & 7);
+                reinterpret_cast<bf16_t *>(j.dst)[total + fi] = nsg_f2bf(v);
+            }
+        } else {
+            reinterpret_cast<float *>(j.dst)[i] = v;
+        }
     }
 }
 
@@ -307,7 +317,9 @@ size_t nsg_packed_weight_floats(const nsg_conv_desc *d)
     const size_t n = (size_t)kh_of(d) * kw_of(d) * d->C_in * d->C_out;
     // the single-channel layers keep one image as fp32 [C][16] for the stencil kernels whatever d->dtype is
     const bool c1 = (!d->transposed && d->C_in == 1) || (d->transposed && d->C_out == 1);
-    return (c1 && d->dtype == NSG_BF16) ? 2 * n : n;
+    // bf16 layers gemm_patch.hip can run carry a second, fragment-ordered image behind each plain one
+    const bool frag = d->dtype == NSG_BF16 && (nsg_frag_image(d->C_out, d->C_in) || nsg_frag_image(d->C_in, d->C_out));
+    return ((c1 && d->dtype == NSG_BF16) || frag) ? 2 * n : n;
 }
 
 int nsg_pack_conv_weights(const nsg_conv_desc *d, const float *w, void *w_fwd, void *w_dgrad, void *stream)
@@ -338,6 +350,7 @@ int nsg_pack_conv_weights_batch(int32_t n, const nsg_conv_desc *descs, const flo
         if (nj == PACK_MAX_JOBS) rc = flush();
         PackJob &j = jobs.job[nj++];
         j.src = src; j.dst = dst; j.T = T; j.NN = NN; j.CC = CC; j.sn = sn; j.sc = sc; j.flip = flip; j.bf16 = bf;
+        j.frag = (bf && T > 1 && nsg_frag_image(NN, CC)) ? 1 : 0;
         const int64_t total = (int64_t)T * NN * CC;
         if (total > biggest) biggest = total;
     };

@@ -29,7 +29,7 @@
 namespace {
 
 int g_patch_gemm = 1;        // nsg_debug_set_patch_gemm: 0 sends everything back to gemm_gather.hip's kernel (A/B runs)
-int g_patch_grid_cap = 0;    // nsg_debug_set_patch_grid: > 0 caps the grid (workgroups then walk several tiles); 0 = one tile each
+int g_patch_grid_cap = 512;  // nsg_debug_set_patch_grid: workgroups per launch (2 per CU resident: each walks tiles with a grid stride); 0 = one tile each
 
 constexpr int PG_MAX_JOBS = 16;
 constexpr int PG_MAX_TAPS = 64;
@@ -43,7 +43,7 @@ struct PatchJob {
 };
 struct PatchTap {
     int delta_bytes;        // LDS byte offset of the tap inside the patch (slot delta * SLOT_BYTES)
-    unsigned woff_bytes;    // byte offset of (weight tap, chunk) in the packed [tap][co][ci] image
+    unsigned woff_bytes;    // byte offset of (weight tap, chunk) in the fragment-ordered image: [tap][chunk][co / 32][4][64 lanes][8]
 };
 
 struct PatchGemmParams {
@@ -61,23 +61,40 @@ struct PatchGemmParams {
     int os;                 // output step (1, or 2 for the transposed form)
     int flags;
     unsigned in_bytes, w_bytes;
+    unsigned long long *stamps;     // diagnostics build only: [workgroup][8] cycle counts (never read by any kernel)
     PatchJob jobs[PG_MAX_JOBS];
     PatchTap taps[PG_MAX_TAPS];
 };
 
-// PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4)
-template <int PH, int PW, int NT>
+// PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4); STAMP: diagnostics build (cycle shares)
+template <int PH, int PW, int NT, bool STAMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
     constexpr int NPIECE = NSLOT * 8;                       // 16-byte pieces of a patch (64 channels = 8 pieces per slot)
     constexpr int NP = (NPIECE + 255) / 256;                // pieces per thread
+    constexpr int PPT = (NP + (NT - 2) - 1) / (NT - 2);     // pieces a thread fetches per tap: spread over the first NT - 2 taps
     constexpr int BUF_BYTES = ((NSLOT * SLOT_BYTES + 255) / 256) * 256;
     constexpr int CPITCH = 132;                             // epilogue staging pitch (floats): [32 pixels][128 channels + 4]
     static_assert(32 * CPITCH * 4 <= BUF_BYTES, "a tile row of the output must fit a retired patch buffer");
+    static_assert(PPT * (NT - 2) >= NP && NT >= 4, "every patch piece is fetched two taps before the job ends");
     constexpr unsigned OOB = 0xfffffff0u;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][BUF_BYTES]
+
+    // diagnostics (STAMP builds only): where a workgroup's cycles go -- tap loops / job boundaries / epilogues / the rest
+    unsigned long long st_entry = 0, st_rt = 0, st_loop = 0, st_bound = 0, st_flush = 0, st_pro = 0, st_jobs = 0, st_t = 0;
+    auto now = [&]() -> unsigned long long {
+        if constexpr (STAMP) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            return t;
+        }
+        return 0ull;
+    };
+    if constexpr (STAMP) { st_entry = now(); st_rt = __builtin_amdgcn_s_memrealtime(); }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,29 +105,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
-    // ---- this thread's patch pieces: piece i = tid + 256 r -> slot i >> 3 (yy, xx), 16-byte piece i & 7 ----
-    int pc_yx[NP];                           // (yy << 8) | xx; an invalid slot (the ragged end of the last pass) has yy far outside
-#pragma unroll
-    for (int r = 0; r < NP; ++r) {
-        const int slot = (tid >> 3) + 32 * r;
-        pc_yx[r] = slot < NSLOT ? ((slot / PW) << 8) | (slot % PW) : (0x4000 << 8);
-    }
-    const unsigned pc_lds0 = (unsigned)(tid >> 3) * SLOT_BYTES + (tid & 7) * 16;     // piece r sits 32 slots further per r
-    const int piece_b = (tid & 7) * 16;                      // (256 r is a multiple of 8: the piece index does not depend on r)
+    // ---- this thread's patch pieces: piece r (0 .. NP-1) -> slot (tid >> 3) + 32 r, 16-byte piece tid & 7 of its 128 bytes ----
+    const int slot0 = tid >> 3;
+    const unsigned pc_lds0 = (unsigned)slot0 * SLOT_BYTES + (tid & 7) * 16;     // + r * 32 * SLOT_BYTES
+    const unsigned piece_b = (tid & 7) * 16;
 
     // ---- fragment addressing ----
-    // A operand of the MFMA = weights: lane (r = x31, h) holds w[co = n0 + 32 wave + r][ci = c0 + 16 kk + 8 h .. + 7]
-    const unsigned wlane = (unsigned)(((n0 + 32 * wave + x31) * p.CI + 8 * h) * 2);
+    // A operand of the MFMA = weights: lane (r = x31, h) holds w[co = n0 + 32 wave + r][ci = c0 + 16 kk + 8 h .. + 7], read from
+    // the fragment-ordered image: (tap, chunk) block -> this wave's 32-channel block -> k-step -> lane: 16 bytes each, so one
+    // wave-wide load is 1 KiB contiguous.  (From the plain [tap][co][ci] image the same load touches 32 cache lines for 32
+    // bytes each and the step ran at the vector L1's line rate: SQ counters, DESIGN.md.)
+    const unsigned wlane = (unsigned)((((n0 >> 5) + wave) * 4 * 64 + lane) * 16);
     // B operand = pixels: lane (x31, h) of tile row y reads slot (y PW + x31) + delta, bytes 32 kk + 16 h
     unsigned arow[4];
 #pragma unroll
     for (int y = 0; y < 4; ++y) arow[y] = (unsigned)((y * PW + x31) * SLOT_BYTES + 16 * h);
 
-    // epilogue: this thread's 8-channel group and its bias
-    const int cg = tid & 15;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
+    const int cg = tid & 15;                 // epilogue: this thread's 8-channel group
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
 
     // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
@@ -123,7 +134,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 
     v16f acc[4];
     v4f breg[2][4];          // weight fragments of two taps (4 k-steps of 16 channels each)
-    v4f preg[NP];            // the patch in flight: global -> registers a job ahead of its ds_write
+    v4f afr[4];              // pixel fragments of one k-step (4 tile rows): each is re-read for the next k-step right after its MFMA
+    v4f ptmp[2][PPT];        // patch pieces in flight: fetched in tap t (even / odd half), written to LDS in tap t + 2
 
     // ---- job stream: (tile, job) for this workgroup, tiles bid, bid + grid, ... ----
     const int G = gridDim.x;
@@ -137,43 +149,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         ty = nsg_div(rem, p.div_tx);
         tx = rem - ty * p.tiles_x;
     };
-    auto load_patch = [&](const Cursor &c) {
-        if (c.tile >= p.ntiles) return;                      // past the end of the stream: nothing to fetch (never stored either)
+
+    // The NEXT job's patch is fetched piece by piece inside the current job's taps: global -> a register in tap t, register ->
+    // the OTHER patch buffer in tap t + 2 (that buffer is free: every wave passed the barrier that ended the job reading it).
+    // vmcnt retires in order, so the piece loads are issued right AFTER a tap's weight loads: a weight wait never includes a
+    // patch piece (HBM / Infinity Cache latency) issued less than two taps earlier.
+    int pt_ok = 0, pt_iy0 = 0, pt_ix0 = 0;
+    unsigned pt_base = 0;
+    auto patch_origin = [&](const Cursor &c) {
+        pt_ok = c.tile < p.ntiles;
         int b, ty, tx;
-        tile_origin(c.tile, b, ty, tx);
+        tile_origin(pt_ok ? c.tile : 0, b, ty, tx);
         const PatchJob jb = p.jobs[c.job];
-        const int iy0 = ty * 4 * p.sy + jb.jy, ix0 = tx * 32 * p.sx + jb.jx;
-        const unsigned cb = (unsigned)(jb.c0_bytes + piece_b);
+        pt_iy0 = ty * 4 * p.sy + jb.jy;
+        pt_ix0 = tx * 32 * p.sx + jb.jx;
+        pt_base = (unsigned)(b * p.IH * p.IW) * (unsigned)p.CI * 2u + (unsigned)jb.c0_bytes;     // (< 4 GiB: the launcher checks)
+    };
+    auto load_piece = [&](int r) -> v4f {    // r: uniform, may be a run-time value
+        const int slot = slot0 + 32 * r;
+        const int yy = slot / PW, xx = slot - yy * PW;
+        const int iy = pt_iy0 + yy * p.sy, ix = pt_ix0 + xx * p.sx;
+        const bool ok = (slot < NSLOT) & (iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW) & (pt_ok != 0);
+        const unsigned off = ok ? pt_base + (unsigned)((iy * p.IW + ix) * p.CI) * 2u + piece_b : OOB;
+        return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
+    };
+    auto store_piece = [&](int buf, int r, const v4f v) {
+        if (NPIECE % 256 == 0 || tid + 256 * r < NPIECE) *reinterpret_cast<v4f *>(smem + buf * BUF_BYTES + pc_lds0 + r * 32 * SLOT_BYTES) = v;
+    };
+    // tap t of a job reading buffer `buf` (t: run-time, uniform; HALF = t & 1 at compile time)
+    auto patch_traffic = [&](auto HALF, int t, int buf) {
+        constexpr int hf = decltype(HALF)::value;
+        if (t >= 2) {
 #pragma unroll
-        for (int r = 0; r < NP; ++r) {
-            const int iy = iy0 + (pc_yx[r] >> 8) * p.sy, ix = ix0 + (pc_yx[r] & 255) * p.sx;
-            const bool ok = (iy >= 0) & (iy < p.IH) & (ix >= 0) & (ix < p.IW);
-            const unsigned off = ok ? (unsigned)(((b * p.IH + iy) * p.IW + ix) * p.CI) * 2u + cb : OOB;
-            preg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
+            for (int i = 0; i < PPT; ++i)
+                if ((t - 2) * PPT + i < NP) store_piece(buf ^ 1, (t - 2) * PPT + i, ptmp[hf][i]);
+        }
+        if (t <= NT - 3) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                if (t * PPT + i < NP) ptmp[hf][i] = load_piece(t * PPT + i);
         }
     };
-    auto store_patch = [&](int buf) {
-        char *base = smem + buf * BUF_BYTES;
-#pragma unroll
-        for (int r = 0; r < NP; ++r)
-            if (NPIECE % 256 == 0 || r + 1 < NP || tid + 256 * r < NPIECE) *reinterpret_cast<v4f *>(base + pc_lds0 + r * 32 * SLOT_BYTES) = preg[r];
-    };
+
     auto load_b = [&](v4f (&bq)[4], int q) {
         const int so = tap_woff(q);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 32 * kk), (int)so, 0));
+            bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 1024 * kk), so, 0));
     };
-    v4f afr[4];              // pixel fragments of one k-step (4 tile rows): each is re-read for the next k-step right after its MFMA
     auto read_a1 = [&](int y, int buf, int q, int kk) {
         afr[y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 32 * kk + arow[y]);
     };
     // One tap = 4 k-steps of 16 channels.  On entry afr holds k-step 0 of tap q; on exit k-step 0 of tap qn.  At the end of
     // a job qn = q: the next patch is not visible before the job-boundary barrier, so the read is a dummy (branch-free) and
     // run_job reads the real fragments after the barrier.
-    auto compute_tap = [&](const v4f (&bq)[4], v4f (&bnext)[4], int buf, int q, int qn, int qb) {
-        load_b(bnext, qb);                                  // the weight fragments of the tap after this one: a whole tap to land
-        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);  // (pinned here: left alone, the scheduler sinks them to their first use)
+    auto mfma_chain = [&](const v4f (&bq)[4], int buf, int q, int qn) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -190,6 +220,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             }
         }
     };
+    // A tap: the weight fragments of the tap after it (a whole tap to land), this tap's share of the patch traffic, the MFMAs.
+    auto tap = [&](auto HALF, const v4f (&bq)[4], v4f (&bnext)[4], int buf, int t, int q, int qn, int qb) {
+        load_b(bnext, qb);
+        __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the loads to their first use)
+        patch_traffic(HALF, t, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chain(bq, buf, q, qn);
+    };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int y = 0; y < 4; ++y)
@@ -197,11 +235,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
     };
 
-    // ---- epilogue of one output class of one tile: four passes (one tile row each) through the retired patch buffer ----
+    // ---- epilogue of one output class of one tile: four passes (one tile row each) through the retired patch buffer; the
+    //      fused operands of all four passes are fetched before the first ----
     auto flush = [&](int tile, const PatchJob &jb, int buf) {
         int b, ty, tx;
         tile_origin(tile, b, ty, tx);
         float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
         // this thread's 8 output pieces: tile row y, pixel (tid >> 4) + 16 e2, channels 8 cg .. + 7
         int off[4][2];
         v4f addv[4][2], maskv[4][2];
@@ -271,53 +313,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     }
     Cursor cur = {bid, 0};                  // job being computed
-    Cursor pre = cur;                       // job whose patch is being fetched
+    Cursor pre = cur;                       // job whose patch is being fetched (one ahead of cur inside the loop)
     if (cur.tile >= p.ntiles) return;
-    load_patch(pre);
-    store_patch(0);
-    advance(pre);
-    load_patch(pre);                        // job 1 -> registers
+    patch_origin(pre);
+    for (int r = 0; r < NP; ++r) store_piece(0, r, load_piece(r));      // the first patch: nothing to overlap it with
     load_b(breg[0], 0);
     zero_acc();
     __syncthreads();
     int buf = 0;
     int par = 0;                            // which breg holds the current tap
-    // One job: NT taps from patch buffer `buf`; weight fragments of tap q + 1 (wrapping: the weights do not depend on the tile)
-    // are fetched while tap q runs.  P = parity of the job's first tap in the breg pair (NT odd flips it every job).
+    // One job: NT taps from patch buffer `buf`.  P = parity of the job's first tap in the breg pair (NT odd flips it every job).
     auto run_job = [&](auto PAR, int qbase, int qnext_base) {
         constexpr int P = decltype(PAR)::value;
 #pragma unroll
         for (int y = 0; y < 4; ++y) read_a1(y, buf, qbase, 0);
 #pragma unroll 1
-        for (int t = 0; t + 1 < NT; t += 2) {       // taps in pairs: the two breg halves swap roles inside the body
-            compute_tap(breg[P], breg[P ^ 1], buf, qbase + t, qbase + t + 1, qbase + t + 1);
+        for (int t = 0; t + 1 < NT; t += 2) {       // taps in pairs: the two breg halves (and ptmp halves) swap roles inside the body
+            tap(std::integral_constant<int, 0>{}, breg[P], breg[P ^ 1], buf, t, qbase + t, qbase + t + 1, qbase + t + 1);
             const int q2 = t + 2 < NT ? qbase + t + 2 : qnext_base;
-            compute_tap(breg[P ^ 1], breg[P], buf, qbase + t + 1, t + 2 < NT ? qbase + t + 2 : qbase + t + 1, q2);
+            tap(std::integral_constant<int, 1>{}, breg[P ^ 1], breg[P], buf, t + 1, qbase + t + 1, t + 2 < NT ? qbase + t + 2 : qbase + t + 1, q2);
         }
-        if constexpr (NT & 1) compute_tap(breg[P], breg[P ^ 1], buf, qbase + NT - 1, qbase + NT - 1, qnext_base);
+        if constexpr (NT & 1) tap(std::integral_constant<int, 0>{}, breg[P], breg[P ^ 1], buf, NT - 1, qbase + NT - 1, qbase + NT - 1, qnext_base);
     };
+    if constexpr (STAMP) st_pro = now() - st_entry;
     while (cur.tile < p.ntiles) {
+        if constexpr (STAMP) st_t = now();
         const PatchJob jb = p.jobs[cur.job];
+        advance(pre);
+        patch_origin(pre);                  // its pieces are fetched inside this job's taps
         const int qbase = cur.job * NT;
         const int qnext = (cur.job + 1 == p.njobs ? 0 : cur.job + 1) * NT;
         if (par) run_job(std::integral_constant<int, 1>{}, qbase, qnext);
         else     run_job(std::integral_constant<int, 0>{}, qbase, qnext);
         par = (par + NT) & 1;
-        // job boundary: the next job's patch (in registers since the start of this job) goes to the other buffer
-        store_patch(buf ^ 1);
-        __syncthreads();                    // every wave is done with `buf`; the next patch is visible
-        advance(pre);
-        load_patch(pre);                    // two jobs ahead, lands during the next job
+        if constexpr (STAMP) { const unsigned long long t = now(); st_loop += t - st_t; st_t = t; st_jobs += 1; }
+        __syncthreads();                    // job boundary: every wave is done with `buf`; the next patch (other buffer) is complete
+        if constexpr (STAMP) { const unsigned long long t = now(); st_bound += t - st_t; st_t = t; }
         if (jb.flush) {
             flush(cur.tile, jb, buf);
             zero_acc();
+            if constexpr (STAMP) { const unsigned long long t = now(); st_flush += t - st_t; st_t = t; }
         }
         advance(cur);
         buf ^= 1;
     }
+    if constexpr (STAMP) {
+        if (tid == 0 && p.stamps) {
+            unsigned long long *o = p.stamps + 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = now() - st_entry; o[1] = __builtin_amdgcn_s_memrealtime() - st_rt; o[2] = st_loop; o[3] = st_bound;
+            o[4] = st_flush; o[5] = st_pro; o[6] = st_jobs; o[7] = 0;
+        }
+    }
 }
 
-template <int PH, int PW, int NT>
+template <int PH, int PW, int NT, bool STAMP = false>
 int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
@@ -325,14 +374,14 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
     const size_t lds = 2 * BUF_BYTES;
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, STAMP>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
     int gx = p.ntiles;
     const int cap = g_patch_grid_cap > 0 ? g_patch_grid_cap : 0;
     if (cap > 0 && gx > cap) gx = cap;
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }
 
@@ -347,7 +396,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     *handled = false;
     if (!g_patch_gemm) return NSG_OK;
     if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return NSG_OK;
-    if ((g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) || g.stats || g.stamps) return NSG_OK;
+    if ((g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) || g.stats) return NSG_OK;
     if (g.CI % 64 != 0 || g.CO % 128 != 0) return NSG_OK;
     const int chunks = g.CI / 64;
     int kind;    // 0: 3x3 stride 1, 1: 4x4 stride 2 pad 1, 2: transposed 4/2/1
@@ -361,7 +410,9 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
 
     PatchGemmParams p = {};
     p.in = reinterpret_cast<const bf16_t *>(g.in);
-    p.w = reinterpret_cast<const bf16_t *>(g.w);
+    const int64_t wtaps = g.mode == 0 ? g.KH * g.KW : 16;
+    const int64_t image = wtaps * g.CO * g.CI;                      // elements of the plain image; the fragment-ordered twin follows it
+    p.w = reinterpret_cast<const bf16_t *>(g.w) + image;
     p.bias = g.bias;
     p.out = reinterpret_cast<bf16_t *>(g.out);
     p.epi_add = reinterpret_cast<const bf16_t *>(g.epi_add);
@@ -379,14 +430,16 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     p.os = kind == 2 ? 2 : 1;
     p.flags = g.flags;
     p.in_bytes = g.in_bytes; p.w_bytes = g.w_bytes;
-    const int64_t tapstride = (int64_t)g.CO * g.CI;     // elements per weight tap
+    p.stamps = g.stamps;
+    const int64_t blk = (int64_t)(g.CO / 32) * 4096;    // bytes of one (tap, 64-channel chunk) block of the fragment-ordered image
+    auto wblock = [&](int ws, int c) { return (unsigned)(((int64_t)ws * chunks + c) * blk); };
     int j = 0;
     if (kind == 0) {
         for (int c = 0; c < chunks; ++c, ++j) {
             p.jobs[j] = PatchJob{c * 128, (short)-g.pad, (short)-g.pad_w, 0, 0, c + 1 == chunks};
             for (int kh = 0; kh < 3; ++kh)
                 for (int kw = 0; kw < 3; ++kw)
-                    p.taps[j * 9 + kh * 3 + kw] = PatchTap{(kh * 34 + kw) * SLOT_BYTES, (unsigned)(((kh * 3 + kw) * tapstride + c * 64) * 2)};
+                    p.taps[j * 9 + kh * 3 + kw] = PatchTap{(kh * 34 + kw) * SLOT_BYTES, wblock(kh * 3 + kw, c)};
         }
     } else if (kind == 1) {
         for (int c = 0; c < chunks; ++c)
@@ -396,7 +449,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b)
                         p.taps[j * 4 + a * 2 + b] = PatchTap{(a * 33 + b) * SLOT_BYTES,
-                                                           (unsigned)((((2 * a + ph) * 4 + (2 * b + pw)) * tapstride + c * 64) * 2)};
+                                                           wblock((2 * a + ph) * 4 + (2 * b + pw), c)};
             }
     } else {
         for (int cls = 0; cls < 4; ++cls) {
@@ -406,12 +459,16 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b)
                         p.taps[j * 4 + a * 2 + b] = PatchTap{((1 - a) * 33 + (1 - b)) * SLOT_BYTES,
-                                                           (unsigned)(((((1 - py) + 2 * a) * 4 + (1 - px) + 2 * b) * tapstride + c * 64) * 2)};
+                                                           wblock(((1 - py) + 2 * a) * 4 + (1 - px) + 2 * b, c)};
             }
         }
     }
     *handled = true;
     const int ntn = g.CO / 128;
+    if (g.stamps) {     // diagnostics build of the same kernel (scripts/patch_gemm_shares.py)
+        if (kind == 0) return launch_patch<6, 34, 9, true>(p, ntn, s);
+        return launch_patch<5, 33, 4, true>(p, ntn, s);
+    }
     if (kind == 0) return launch_patch<6, 34, 9>(p, ntn, s);
     return launch_patch<5, 33, 4>(p, ntn, s);
 }

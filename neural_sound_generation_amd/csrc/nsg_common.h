@@ -204,6 +204,8 @@ struct WgradParams {
     int stagger;                 // s_sleep units (64 cycles) the second-dispatched half of the grid waits at start
 };
 
+// A packed bf16 weight image [taps][NN][CC] is followed by its fragment-ordered twin (conv_api.hip: PackJob::frag) when:
+static inline bool nsg_frag_image(int NN, int CC) { return NN % 128 == 0 && CC % 64 == 0; }
 int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
 // gemm_patch.hip: the patch-staged bf16 kernel for the shapes it implements (3x3/1, 4x4/2 and the transposed 4/2/1 with
 // C_in % 64 == 0, C_out % 128 == 0, bf16 in and out); p must have in_bytes / w_bytes filled in.  *handled = false -> not run.
