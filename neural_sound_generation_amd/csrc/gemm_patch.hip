@@ -66,8 +66,10 @@ struct PatchGemmParams {
     PatchTap taps[PG_MAX_TAPS];
 };
 
-// PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4); STAMP: diagnostics build (cycle shares)
-template <int PH, int PW, int NT, bool STAMP = false>
+// PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4); ADD / MASK: the fused epilogue operands are
+// compile-time (a run-time "maybe a load" makes hipcc guard every reuse of the destination registers with a conservative
+// vmcnt that also waits for the tile's own STORES -- the epilogue then runs at store-acknowledge latency); STAMP: diagnostics
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
@@ -121,7 +123,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 #pragma unroll
     for (int y = 0; y < 4; ++y) arow[y] = (unsigned)((y * PW + x31) * SLOT_BYTES + 16 * h);
 
-    const int cg = tid & 15;                 // epilogue: this thread's 8-channel group
+    const int cg = tid & 15;                 // epilogue: this thread's 8-channel group and its bias
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
 
     // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
@@ -131,6 +136,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     static_assert(PG_MAX_TAPS <= 64, "one lane per table entry");
     auto tap_delta = [&](int q) { return __builtin_amdgcn_readlane(tab_delta, q); };
     auto tap_woff = [&](int q) { return __builtin_amdgcn_readlane(tab_woff, q); };
+    // the job table the same way (lane j = job j): a run-time index into the by-value parameter struct from inside the job
+    // lambdas made hipcc copy the whole struct to scratch
+    const PatchJob myjob = p.jobs[lane & (PG_MAX_JOBS - 1)];
+    const int tabj_c0 = myjob.c0_bytes;
+    const int tabj_j = ((int)myjob.jy & 0xffff) | ((int)myjob.jx << 16);
+    const int tabj_o = (int)myjob.oy | ((int)myjob.ox << 8) | (myjob.flush << 16);
+    auto job_entry = [&](int j) {
+        const int c0 = __builtin_amdgcn_readlane(tabj_c0, j), jj = __builtin_amdgcn_readlane(tabj_j, j), oo = __builtin_amdgcn_readlane(tabj_o, j);
+        return PatchJob{c0, (short)(jj & 0xffff), (short)(jj >> 16), (short)(oo & 0xff), (short)((oo >> 8) & 0xff), (oo >> 16) & 1};
+    };
 
     v16f acc[4];
     v4f breg[2][4];          // weight fragments of two taps (4 k-steps of 16 channels each)
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         pt_ok = c.tile < p.ntiles;
         int b, ty, tx;
         tile_origin(pt_ok ? c.tile : 0, b, ty, tx);
-        const PatchJob jb = p.jobs[c.job];
+        const PatchJob jb = job_entry(c.job);
         pt_iy0 = ty * 4 * p.sy + jb.jy;
         pt_ix0 = tx * 32 * p.sx + jb.jx;
         pt_base = (unsigned)(b * p.IH * p.IW) * (unsigned)p.CI * 2u + (unsigned)jb.c0_bytes;     // (< 4 GiB: the launcher checks)
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         if (NPIECE % 256 == 0 || tid + 256 * r < NPIECE) *reinterpret_cast<v4f *>(smem + buf * BUF_BYTES + pc_lds0 + r * 32 * SLOT_BYTES) = v;
     };
     // tap t of a job reading buffer `buf` (t: run-time, uniform; HALF = t & 1 at compile time)
-    auto patch_traffic = [&](auto HALF, int t, int buf) {
+    auto patch_traffic = [&](auto HALF, int t, int buf) __attribute__((always_inline)) {
         constexpr int hf = decltype(HALF)::value;
         if (t >= 2) {
 #pragma unroll
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     // One tap = 4 k-steps of 16 channels.  On entry afr holds k-step 0 of tap q; on exit k-step 0 of tap qn.  At the end of
     // a job qn = q: the next patch is not visible before the job-boundary barrier, so the read is a dummy (branch-free) and
     // run_job reads the real fragments after the barrier.
-    auto mfma_chain = [&](const v4f (&bq)[4], int buf, int q, int qn) {
+    auto mfma_chain = [&](const v4f (&bq)[4], int buf, int q, int qn) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         }
     };
     // A tap: the weight fragments of the tap after it (a whole tap to land), this tap's share of the patch traffic, the MFMAs.
-    auto tap = [&](auto HALF, const v4f (&bq)[4], v4f (&bnext)[4], int buf, int t, int q, int qn, int qb) {
+    auto tap = [&](auto HALF, const v4f (&bq)[4], v4f (&bnext)[4], int buf, int t, int q, int qn, int qb) __attribute__((always_inline)) {
         load_b(bnext, qb);
         __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the loads to their first use)
         patch_traffic(HALF, t, buf);
@@ -236,16 +251,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     };
 
     // ---- epilogue of one output class of one tile: four passes (one tile row each) through the retired patch buffer; the
-    //      fused operands of all four passes are fetched before the first ----
-    auto flush = [&](int tile, const PatchJob &jb, int buf) {
+    //      fused operands of all four passes are fetched before the first.  Branch-free on purpose: output and fused operands
+    //      go through buffer descriptors (an out-of-range offset drops the store / reads zero), because at every branch join
+    //      hipcc's wait-count model turns pessimistic and guards the next register reuse with vmcnt(0) -- which also waits for
+    //      the tile's own STORES: the epilogue then ran at store-acknowledge latency (8 K cycles per tile). ----
+    const unsigned out_bytes = (unsigned)(p.B * p.OH * p.OW) * (unsigned)p.CO * 2u;          // (< 4 GiB: the launcher checks)
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(ADD ? p.epi_add : p.out), 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(MASK ? p.epi_mask : p.out), 0, (int)out_bytes, 0x00020000);
+    auto flush = [&](int tile, const PatchJob &jb, int buf) __attribute__((always_inline)) {
         int b, ty, tx;
         tile_origin(tile, b, ty, tx);
         float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
         // this thread's 8 output pieces: tile row y, pixel (tid >> 4) + 16 e2, channels 8 cg .. + 7
-        int off[4][2];
+        unsigned off[4][2];     // BYTE offsets; OOB for pixels outside the image
         v4f addv[4][2], maskv[4][2];
 #pragma unroll
         for (int y = 0; y < 4; ++y)
@@ -253,19 +272,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             for (int e2 = 0; e2 < 2; ++e2) {
                 const int oy = (ty * 4 + y) * p.os + jb.oy;
                 const int ox = (tx * 32 + (tid >> 4) + 16 * e2) * p.os + jb.ox;
-                off[y][e2] = (oy < p.OH && ox < p.OW) ? ((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + 8 * cg : -1;   // (< 2^31: the launcher checks)
+                off[y][e2] = (oy < p.OH && ox < p.OW) ? (unsigned)(((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + 8 * cg) * 2u : OOB;
             }
-        if (p.epi_add) {        // the skip-path gradient (the ResBlock's residual add, backward): all 8 pieces in flight at once
+        if constexpr (ADD) {    // the skip-path gradient (the ResBlock's residual add, backward): all 8 pieces in flight at once
 #pragma unroll
             for (int y = 0; y < 4; ++y)
 #pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) addv[y][e2] = *reinterpret_cast<const v4f *>(p.epi_add + (off[y][e2] < 0 ? 0 : off[y][e2]));
+                for (int e2 = 0; e2 < 2; ++e2) addv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off[y][e2], 0, 0));
         }
-        if (p.epi_mask) {       // the ReLU whose OUTPUT is epi_mask
+        if constexpr (MASK) {   // the ReLU whose OUTPUT is epi_mask
 #pragma unroll
             for (int y = 0; y < 4; ++y)
 #pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) maskv[y][e2] = *reinterpret_cast<const v4f *>(p.epi_mask + (off[y][e2] < 0 ? 0 : off[y][e2]));
+                for (int e2 = 0; e2 < 2; ++e2) maskv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (int)off[y][e2], 0, 0));
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
@@ -277,7 +296,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             __syncthreads();
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
-                if (off[y][e2] < 0) continue;
                 const int px = (tid >> 4) + 16 * e2;
                 const v4f t0 = *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg);
                 const v4f t1 = *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg + 4);
@@ -286,19 +304,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
                 for (int e = 0; e < 8; ++e) v[e] += bv[e];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];
-                if (p.epi_add) {
+                if constexpr (ADD) {
                     float t[8];
                     Elem<bf16_t>::unpack16(addv[y][e2], t);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += t[e];
                 }
-                if (p.epi_mask) {
+                if constexpr (MASK) {
                     float t[8];
                     Elem<bf16_t>::unpack16(maskv[y][e2], t);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
                 }
-                Elem<bf16_t>::store16(p.out + off[y][e2], v);
+                unsigned u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)off[y][e2], 0, 0);
             }
             __syncthreads();        // the staging rows are rewritten by the next pass (or by the next patch)
         }
@@ -321,9 +343,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     zero_acc();
     __syncthreads();
     int buf = 0;
-    int par = 0;                            // which breg holds the current tap
     // One job: NT taps from patch buffer `buf`.  P = parity of the job's first tap in the breg pair (NT odd flips it every job).
-    auto run_job = [&](auto PAR, int qbase, int qnext_base) {
+    auto run_job = [&](auto PAR, int qbase, int qnext_base) __attribute__((always_inline)) {
         constexpr int P = decltype(PAR)::value;
 #pragma unroll
         for (int y = 0; y < 4; ++y) read_a1(y, buf, qbase, 0);
@@ -336,16 +357,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         if constexpr (NT & 1) tap(std::integral_constant<int, 0>{}, breg[P], breg[P ^ 1], buf, NT - 1, qbase + NT - 1, qbase + NT - 1, qnext_base);
     };
     if constexpr (STAMP) st_pro = now() - st_entry;
-    while (cur.tile < p.ntiles) {
+    // One job of the stream.  With an odd tap count the breg halves swap roles from one job to the next: the loop body below
+    // is then TWO jobs (parities 0 and 1) so that the roles are static per code position -- with a run-time parity hipcc
+    // merged the two variants by moving the prefetched fragments between registers behind an s_waitcnt vmcnt(0) per job.
+    auto do_job = [&](auto PAR) __attribute__((always_inline)) {
         if constexpr (STAMP) st_t = now();
-        const PatchJob jb = p.jobs[cur.job];
+        const PatchJob jb = job_entry(cur.job);
         advance(pre);
         patch_origin(pre);                  // its pieces are fetched inside this job's taps
         const int qbase = cur.job * NT;
         const int qnext = (cur.job + 1 == p.njobs ? 0 : cur.job + 1) * NT;
-        if (par) run_job(std::integral_constant<int, 1>{}, qbase, qnext);
-        else     run_job(std::integral_constant<int, 0>{}, qbase, qnext);
-        par = (par + NT) & 1;
+        run_job(PAR, qbase, qnext);
         if constexpr (STAMP) { const unsigned long long t = now(); st_loop += t - st_t; st_t = t; st_jobs += 1; }
         __syncthreads();                    // job boundary: every wave is done with `buf`; the next patch (other buffer) is complete
         if constexpr (STAMP) { const unsigned long long t = now(); st_bound += t - st_t; st_t = t; }
@@ -356,6 +378,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         }
         advance(cur);
         buf ^= 1;
+    };
+    for (;;) {
+        if (cur.tile >= p.ntiles) break;
+        do_job(std::integral_constant<int, 0>{});
+        if constexpr (NT & 1) {
+            if (cur.tile >= p.ntiles) break;
+            do_job(std::integral_constant<int, 1>{});
+        }
     }
     if constexpr (STAMP) {
         if (tid == 0 && p.stamps) {
@@ -366,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
 }
 
-template <int PH, int PW, int NT, bool STAMP = false>
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false>
 int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
@@ -374,15 +404,24 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
     const size_t lds = 2 * BUF_BYTES;
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, STAMP>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
     int gx = p.ntiles;
     const int cap = g_patch_grid_cap > 0 ? g_patch_grid_cap : 0;
     if (cap > 0 && gx > cap) gx = cap;
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
+}
+
+template <int PH, int PW, int NT, bool STAMP>
+int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
+{
+    if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, STAMP>(p, ntiles_n, s);
+    if (p.epi_add) return launch_patch<PH, PW, NT, true, false, STAMP>(p, ntiles_n, s);
+    if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, STAMP>(p, ntiles_n, s);
+    return launch_patch<PH, PW, NT, false, false, STAMP>(p, ntiles_n, s);
 }
 
 }  // namespace
@@ -466,9 +505,9 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     *handled = true;
     const int ntn = g.CO / 128;
     if (g.stamps) {     // diagnostics build of the same kernel (scripts/patch_gemm_shares.py)
-        if (kind == 0) return launch_patch<6, 34, 9, true>(p, ntn, s);
-        return launch_patch<5, 33, 4, true>(p, ntn, s);
+        if (kind == 0) return launch_patch_epi<6, 34, 9, true>(p, ntn, s);
+        return launch_patch_epi<5, 33, 4, true>(p, ntn, s);
     }
-    if (kind == 0) return launch_patch<6, 34, 9>(p, ntn, s);
-    return launch_patch<5, 33, 4>(p, ntn, s);
+    if (kind == 0) return launch_patch_epi<6, 34, 9, false>(p, ntn, s);
+    return launch_patch_epi<5, 33, 4, false>(p, ntn, s);
 }
