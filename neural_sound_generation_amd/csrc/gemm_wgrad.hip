@@ -799,10 +799,18 @@ int launch_wg(const WgradParams &p, int nslab, hipStream_t s)
 
 }  // namespace
 
+// gemm_wgrad_strip.hip: the row-strip kernel for the bf16 3x3/1 and 4x4/2 layers with channels in multiples of 128
+int nsg_wgrad_strip_slabs(int ntaps, int A, int C);
+bool nsg_wgrad_strip_applicable(const WgradParams &p);
+int nsg_launch_wgrad_strip(const WgradParams &p, int *nslab, hipStream_t s);
+
 size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C)
 {
     const SlabPlan sp = plan_slabs(Mp, ntaps, A, C);
-    return (size_t)sp.nslab * ntaps * A * C * sizeof(float);
+    int nslab = sp.nslab;
+    if ((ntaps == 9 || ntaps == 16) && A % 128 == 0 && C % 128 == 0 && nsg_wgrad_strip_slabs(ntaps, A, C) > nslab)
+        nslab = nsg_wgrad_strip_slabs(ntaps, A, C);       // whichever kernel runs, its slabs fit
+    return (size_t)nslab * ntaps * A * C * sizeof(float);
 }
 
 int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipStream_t s)
@@ -813,8 +821,8 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     const int epv = (!p.onehot && p.dtype == NSG_BF16) ? 8 : 4;
     if ((!p.onehot && p.A % epv != 0) || p.C % epv != 0) return nsg_fail(NSG_E_UNSUPPORTED, "wgrad: channels (%d,%d) must be multiples of %d", p.A, p.C, epv);
     if ((!p.onehot && !nsg_aligned16(p.P)) || !nsg_aligned16(p.Q)) return nsg_fail(NSG_E_INVALID, "wgrad: operands must be 16-byte aligned");
-    const SlabPlan sp = plan_slabs(p.Mp, ntaps, p.A, p.C);
-    const size_t need = (size_t)sp.nslab * ntaps * p.A * p.C * sizeof(float);
+    SlabPlan sp = plan_slabs(p.Mp, ntaps, p.A, p.C);
+    const size_t need = nsg_wgrad_workspace_bytes(p.Mp, ntaps, p.A, p.C);
     if (ws == nullptr || ws_bytes < need) return nsg_fail(NSG_E_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     p.partial = reinterpret_cast<float *>(ws);
     p.slab_rows = sp.slab_rows;
@@ -835,7 +843,9 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
     p.div_pw = nsg_fastdiv((uint32_t)p.PW);
     p.div_phw = nsg_fastdiv((uint32_t)p.PH * (uint32_t)p.PW);
     int rc;
-    if (p.C <= 32) {
+    if (nsg_wgrad_strip_applicable(p)) {
+        rc = nsg_launch_wgrad_strip(p, &sp.nslab, s);        // one kernel row per workgroup, strips of 64 pixels (gemm_wgrad_strip.hip)
+    } else if (p.C <= 32) {
         rc = launch_wg<4, 1, 1, 1>(p, sp.nslab, s);          // 128 x 32 (im2col'd single-channel layers)
     } else if (p.A <= 64 && p.C <= 64) {
         rc = launch_wg<2, 2, 1, 1>(p, sp.nslab, s);          // 64 x 64

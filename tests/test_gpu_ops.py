@@ -480,11 +480,23 @@ def test_patch_staged_conv_kernel(case):
                 ops.conv_dgrad(d, dyg, wd), ops.conv_dgrad(d, dyg, wd, add=skip, relu_x=rx))
     new = run()
     again = run()
+    dw_new, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)      # gemm_wgrad_strip.hip when both channel counts are multiples of 128
+    dw_again, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)
     lib.nsg_debug_set_patch_gemm(0)
+    lib.nsg_debug_set_wgrad_strip(0)
     try:
         old = run()
+        dw_old, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)
     finally:
         lib.nsg_debug_set_patch_gemm(1)
+        lib.nsg_debug_set_wgrad_strip(1)
+    # weight gradient: fp32 out, against ATen on the same bf16-rounded operands and against the per-tap kernel
+    wr = wq.clone().requires_grad_(True)
+    yw = F.conv_transpose2d(x, wr, None, stride=s, padding=p) if tr else F.conv2d(x, wr, None, stride=s, padding=p)
+    gw, = torch.autograd.grad(yw, [wr], dy)
+    assert torch.equal(dw_new, dw_again), "the weight gradient must be bitwise reproducible"
+    _close(dw_new.cpu(), gw, tol=2e-3, what="wgrad")
+    _close(dw_new.cpu(), dw_old.cpu(), tol=1e-5, what="wgrad vs the per-tap kernel (same bf16 products, fp32 sums in another order)")
     for a, c in zip(new, again):
         assert torch.equal(a, c), "the patch-staged kernel must be bitwise reproducible"
     _close(nchw(new[0].float().cpu()), y.detach(), tol=1e-2, what="forward")
