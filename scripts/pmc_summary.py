@@ -61,8 +61,9 @@ def main():
             table[k] = {"launches": len(v), "hbm_bytes_per_launch": (2 * fe + wr) * 1024}
             w.writerow([k, len(v), f"{fe:.1f}", f"{wr:.1f}", f"{mb:.1f}"])
     # dominant kernel: the 128x128 gather_gemm instantiations of this dtype (the launches bench.py times), launch-weighted
+    # (bf16: the patch-staged kernel of gemm_patch.hip runs every 3x3 / 4x4 conv forward and data gradient of the step)
     el = "bf16, bf16" if dtype == "bf16" else "float, float"
-    gg = {k: v for k, v in table.items() if k.startswith(f"gather_gemm_kernel<{el}, 2, 2, 2, 2")}
+    gg = {k: v for k, v in table.items() if k.startswith(f"gather_gemm_kernel<{el}, 2, 2, 2, 2") or (dtype == "bf16" and k.startswith("patch_gemm_kernel<"))}
     n = sum(v["launches"] for v in gg.values())
     avg = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in gg.values()) / max(1, n)
     latest = os.path.join(out_dir, "pmc_traffic_latest.json")
@@ -71,7 +72,7 @@ def main():
         cur = json.load(open(latest))
         if "hbm_bytes_per_launch" in cur:      # old single-entry layout
             cur = {}
-    cur[dtype] = {"tag": tag, "kernel": f"gather_gemm_kernel<{el}, 128x128>", "launches": n, "hbm_bytes_per_launch": avg,
+    cur[dtype] = {"tag": tag, "kernel": "patch_gemm_kernel<...> (gemm_patch.hip)" if dtype == "bf16" else f"gather_gemm_kernel<{el}, 128x128>", "launches": n, "hbm_bytes_per_launch": avg,
                   "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py --dtype %s; "
                           "bytes=(2*FETCH_SIZE+WRITE_SIZE)*1024" % dtype}
     json.dump(cur, open(latest, "w"), indent=1)

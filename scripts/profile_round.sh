@@ -9,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp
 for DT in bf16 f32; do
   # the timing pass runs bench.py's own default length (20 + 5 steps): its per-kernel averages are comparable with the
   # live HIP-event timer of a plain run; the counter passes only need a few steps
-  SARGS="--dtype $DT --steps 20 --warmup 5 --no-cpu-baseline --no-second-mode --no-kernel-timer"
-  ARGS="--dtype $DT --steps 4 --warmup 2 --no-cpu-baseline --no-second-mode --no-kernel-timer"
+  SARGS="--dtype $DT --steps 20 --warmup 5 --no-cpu-baseline --no-second-mode --no-other-configs --no-kernel-timer"
+  ARGS="--dtype $DT --steps 4 --warmup 2 --no-cpu-baseline --no-second-mode --no-other-configs --no-kernel-timer"
   rocprofv3 --kernel-trace --stats -d $OUT/${DT}_stats -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $SARGS > $OUT/${DT}_stats.log 2>&1
   echo "stats $DT done"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${DT}_fetch -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/${DT}_fetch.log 2>&1
