@@ -62,8 +62,7 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
         if (j.bf16) {
             reinterpret_cast<bf16_t *>(j.dst)[i] = nsg_f2bf(v);
             if (j.frag) {
-                const int64_t fi = ((((int64_t)(t * (j.CC >> 6) + (c >> 6)) * (j.NN >> 5) + (n >> 5)) * 4 + ((c & 63) >> 4)) * 64 + (n & 31) + 32 * ((c & 15) >> 3)) * 8 + (c & 7);
-                reinterpret_cast<bf16_t *>(j.dst)[total + fi] = nsg_f2bf(v);
+                reinterpret_cast<bf16_t *>(j.dst)[total + nsg_frag_index(t, n, c, j.NN, j.CC)] = nsg_f2bf(v);
             }
         } else {
             reinterpret_cast<float *>(j.dst)[i] = v;

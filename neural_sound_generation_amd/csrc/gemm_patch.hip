@@ -33,7 +33,7 @@ int g_patch_grid_cap = 512;  // nsg_debug_set_patch_grid: workgroups per launch 
 
 constexpr int PG_MAX_JOBS = 16;
 constexpr int PG_MAX_TAPS = 64;
-constexpr int SLOT_BYTES = 144;     // 128 bytes of a pixel's 64-channel chunk + 16 bytes of padding (bank spread)
+constexpr int SLOT_BYTES = 16;      // LDS image of a patch chunk: [8 pieces of 16 bytes][slots]: a slot's pieces sit one PLANE apart
 
 struct PatchJob {
     int c0_bytes;       // byte offset of the channel chunk inside a pixel
@@ -69,14 +69,20 @@ struct PatchGemmParams {
 // PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4); ADD / MASK: the fused epilogue operands are
 // compile-time (a run-time "maybe a load" makes hipcc guard every reuse of the destination registers with a conservative
 // vmcnt that also waits for the tile's own STORES -- the epilogue then runs at store-acknowledge latency); STAMP: diagnostics
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false>
+// M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same FLOP per cycle; the chip holds a higher clock on it)
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
     constexpr int NPIECE = NSLOT * 8;                       // 16-byte pieces of a patch (64 channels = 8 pieces per slot)
     constexpr int NP = (NPIECE + 255) / 256;                // pieces per thread
     constexpr int PPT = (NP + (NT - 2) - 1) / (NT - 2);     // pieces a thread fetches per tap: spread over the first NT - 2 taps
-    constexpr int BUF_BYTES = ((NSLOT * SLOT_BYTES + 255) / 256) * 256;
+    // LDS image of a patch chunk: [piece 0..7][slot] x 16 bytes, PLANE a multiple of 256 bytes.  A fragment read takes ONE piece
+    // of 16 (or 32) consecutive slots = consecutive 16-byte bank groups, whatever the tap's shift and for both MFMA shapes
+    // (the lanes of one ds_read_b128 group that differ in piece sit whole PLANEs apart: same bank group as their slot alone).
+    constexpr int NSLOT_PAD = (NSLOT + 15) / 16 * 16;
+    constexpr int PLANE = NSLOT_PAD * 16;
+    constexpr int BUF_BYTES = 8 * PLANE;
     constexpr int CPITCH = 132;                             // epilogue staging pitch (floats): [32 pixels][128 channels + 4]
     static_assert(32 * CPITCH * 4 <= BUF_BYTES, "a tile row of the output must fit a retired patch buffer");
     static_assert(PPT * (NT - 2) >= NP && NT >= 4, "every patch piece is fetched two taps before the job ends");
@@ -107,21 +113,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
-    // ---- this thread's patch pieces: piece r (0 .. NP-1) -> slot (tid >> 3) + 32 r, 16-byte piece tid & 7 of its 128 bytes ----
-    const int slot0 = tid >> 3;
-    const unsigned pc_lds0 = (unsigned)slot0 * SLOT_BYTES + (tid & 7) * 16;     // + r * 32 * SLOT_BYTES
-    const unsigned piece_b = (tid & 7) * 16;
+    // ---- this thread's patch pieces: f = tid + 256 r -> slot (f & 7) + 8 (f >> 6), piece (f >> 3) & 7: eight consecutive lanes
+    //      write eight consecutive slots of one piece plane (conflict-free ds_write_b128) and a wave-wide load still covers
+    //      eight whole 128-byte pixel chunks ----
+    const int slot0 = (tid & 7) + 8 * (tid >> 6);            // + 32 r
+    const unsigned piece_b = ((tid >> 3) & 7) * 16;
+    const unsigned pc_lds0 = ((tid >> 3) & 7) * PLANE + slot0 * 16;     // + r * 32 * 16
 
     // ---- fragment addressing ----
-    // A operand of the MFMA = weights: lane (r = x31, h) holds w[co = n0 + 32 wave + r][ci = c0 + 16 kk + 8 h .. + 7], read from
-    // the fragment-ordered image: (tap, chunk) block -> this wave's 32-channel block -> k-step -> lane: 16 bytes each, so one
-    // wave-wide load is 1 KiB contiguous.  (From the plain [tap][co][ci] image the same load touches 32 cache lines for 32
-    // bytes each and the step ran at the vector L1's line rate: SQ counters, DESIGN.md.)
+    // A operand of the MFMA = weights, read from the fragment-ordered image: (tap, chunk) block -> this wave's 32-channel
+    // block -> four 1 KiB fragments -> lane: 16 bytes each, so one wave-wide load is 1 KiB contiguous.  (From the plain
+    // [tap][co][ci] image the same load touches 32 cache lines for 32 bytes each and the step ran at the vector L1's line
+    // rate: SQ counters, DESIGN.md.)  32x32x16: fragment kk, lane (r = x31, h) = w[co = 32 w + r][ci = 16 kk + 8 h .. + 7];
+    // 16x16x32: fragment 2 cb + ks, lane (i = lane & 15, kq = lane >> 4) = w[co = 32 w + 16 cb + i][ci = 32 ks + 8 kq .. + 7].
     const unsigned wlane = (unsigned)((((n0 >> 5) + wave) * 4 * 64 + lane) * 16);
-    // B operand = pixels: lane (x31, h) of tile row y reads slot (y PW + x31) + delta, bytes 32 kk + 16 h
+    // B operand = pixels.  32x32x16: lane (x31, h) of tile row y reads slot (y PW + x31) + delta, piece 2 kk + h;
+    // 16x16x32: lane (px = lane & 15, kq) of block (y, xh) reads slot (y PW + 16 xh + px) + delta, piece 4 ks + kq.
     unsigned arow[4];
 #pragma unroll
-    for (int y = 0; y < 4; ++y) arow[y] = (unsigned)((y * PW + x31) * SLOT_BYTES + 16 * h);
+    for (int y = 0; y < 4; ++y)
+        arow[y] = M16 ? (unsigned)((y * PW + (lane & 15)) * 16 + (lane >> 4) * PLANE) : (unsigned)((y * PW + x31) * 16 + h * PLANE);
 
     const int cg = tid & 15;                 // epilogue: this thread's 8-channel group and its bias
     float bv[8];
@@ -147,9 +158,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         return PatchJob{c0, (short)(jj & 0xffff), (short)(jj >> 16), (short)(oo & 0xff), (short)((oo >> 8) & 0xff), (oo >> 16) & 1};
     };
 
-    v16f acc[4];
-    v4f breg[2][4];          // weight fragments of two taps (4 k-steps of 16 channels each)
-    v4f afr[4];              // pixel fragments of one k-step (4 tile rows): each is re-read for the next k-step right after its MFMA
+    v16f acc[4];             // 32x32x16: one 32 x 32 tile per tile row.  16x16x32: the same 64 registers as 16 tiles of
+                             // 16 x 16: registers 4 (4 xh + 2 cb ... ) -- see acc16()
+    v4f breg[2][4];          // weight fragments of two taps
+    v4f afr[M16 ? 8 : 4];    // pixel fragments of one k-step: each is re-read for the next k-step right after its last MFMA
     v4f ptmp[2][PPT];        // patch pieces in flight: fetched in tap t (even / odd half), written to LDS in tap t + 2
 
     // ---- job stream: (tile, job) for this workgroup, tiles bid, bid + grid, ... ----
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
     };
     auto store_piece = [&](int buf, int r, const v4f v) {
-        if (NPIECE % 256 == 0 || tid + 256 * r < NPIECE) *reinterpret_cast<v4f *>(smem + buf * BUF_BYTES + pc_lds0 + r * 32 * SLOT_BYTES) = v;
+        if (slot0 + 32 * r < NSLOT) *reinterpret_cast<v4f *>(smem + buf * BUF_BYTES + pc_lds0 + r * 32 * 16) = v;
     };
     // tap t of a job reading buffer `buf` (t: run-time, uniform; HALF = t & 1 at compile time)
     auto patch_traffic = [&](auto HALF, int t, int buf) __attribute__((always_inline)) {
@@ -213,25 +225,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 1024 * kk), so, 0));
     };
     auto read_a1 = [&](int y, int buf, int q, int kk) {
-        afr[y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 32 * kk + arow[y]);
+        afr[y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 2 * kk * PLANE + arow[y]);
     };
-    // One tap = 4 k-steps of 16 channels.  On entry afr holds k-step 0 of tap q; on exit k-step 0 of tap qn.  At the end of
-    // a job qn = q: the next patch is not visible before the job-boundary barrier, so the read is a dummy (branch-free) and
-    // run_job reads the real fragments after the barrier.
+    auto read_a16 = [&](int y, int xh, int buf, int q, int ks) {
+        afr[2 * y + xh] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 4 * ks * PLANE + 256 * xh + arow[y]);
+    };
+    auto read_a_first = [&](int buf, int q) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { read_a16(y, 0, buf, q, 0); read_a16(y, 1, buf, q, 0); }
+        } else {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) read_a1(y, buf, q, 0);
+        }
+    };
+    // One tap.  On entry afr holds the first k-step of tap q; on exit the first k-step of tap qn.  At the end of a job qn = q:
+    // the next patch is not visible before the job-boundary barrier, so the read is a dummy (branch-free) and run_job reads
+    // the real fragments after the barrier.
     auto mfma_chain = [&](const v4f (&bq)[4], int buf, int q, int qn) __attribute__((always_inline)) {
+        if constexpr (M16) {
+            // accumulator of block (y, xh, cb): four floats = registers 4 (2 xh + cb) .. + 3 of acc[y]
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[y]), acc[y], 0, 0, 0);
-                if (kk < 3) read_a1(y, buf, q, kk + 1);
-                else read_a1(y, buf, qn, 0);
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int xh = 0; xh < 2; ++xh) {
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) {
+                            const int o = 4 * (2 * xh + cb);
+                            v4f c4 = {acc[y][o], acc[y][o + 1], acc[y][o + 2], acc[y][o + 3]};
+                            c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[2 * cb + ks]),
+                                                                         __builtin_bit_cast(bf16x8, afr[2 * y + xh]), c4, 0, 0, 0);
+                            acc[y][o] = c4.x; acc[y][o + 1] = c4.y; acc[y][o + 2] = c4.z; acc[y][o + 3] = c4.w;
+                        }
+                        if (ks == 0) read_a16(y, xh, buf, q, 1);
+                        else read_a16(y, xh, buf, qn, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
-            // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next three MFMAs)
+        } else {
 #pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[y]), acc[y], 0, 0, 0);
+                    if (kk < 3) read_a1(y, buf, q, kk + 1);
+                    else read_a1(y, buf, qn, 0);
+                }
+                // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next three MFMAs)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
         }
     };
@@ -290,9 +341,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         for (int y = 0; y < 4; ++y) {
             // this wave's 32 pixels x 32 channels of tile row y: register group g of lane (x, h) = channels 32 w + 8 g + 4 h .. + 3
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<v4f *>(Cs + x31 * CPITCH + 32 * wave + 8 * g + 4 * h) =
-                    v4f{acc[y][4 * g], acc[y][4 * g + 1], acc[y][4 * g + 2], acc[y][4 * g + 3]};
+            for (int g = 0; g < 4; ++g) {
+                // 32x32x16: group g of lane (x, h) = channels 8 g + 4 h .. + 3 of pixel x; 16x16x32: group g = 2 xh + cb of lane
+                // (px, kq) = channels 16 cb + 4 kq .. + 3 of pixel 16 xh + px
+                float *dst = M16 ? Cs + (16 * (g >> 1) + (lane & 15)) * CPITCH + 32 * wave + 16 * (g & 1) + 4 * (lane >> 4)
+                                 : Cs + x31 * CPITCH + 32 * wave + 8 * g + 4 * h;
+                *reinterpret_cast<v4f *>(dst) = v4f{acc[y][4 * g], acc[y][4 * g + 1], acc[y][4 * g + 2], acc[y][4 * g + 3]};
+            }
             __syncthreads();
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
@@ -346,8 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     // One job: NT taps from patch buffer `buf`.  P = parity of the job's first tap in the breg pair (NT odd flips it every job).
     auto run_job = [&](auto PAR, int qbase, int qnext_base) __attribute__((always_inline)) {
         constexpr int P = decltype(PAR)::value;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) read_a1(y, buf, qbase, 0);
+        read_a_first(buf, qbase);
 #pragma unroll 1
         for (int t = 0; t + 1 < NT; t += 2) {       // taps in pairs: the two breg halves (and ptmp halves) swap roles inside the body
             tap(std::integral_constant<int, 0>{}, breg[P], breg[P ^ 1], buf, t, qbase + t, qbase + t + 1, qbase + t + 1);
@@ -396,32 +450,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
 }
 
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false>
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false>
 int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
-    constexpr size_t BUF_BYTES = ((NSLOT * SLOT_BYTES + 255) / 256) * 256;
+    constexpr size_t BUF_BYTES = (size_t)8 * ((NSLOT + 15) / 16 * 16) * 16;
     const size_t lds = 2 * BUF_BYTES;
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
     int gx = p.ntiles;
     const int cap = g_patch_grid_cap > 0 ? g_patch_grid_cap : 0;
     if (cap > 0 && gx > cap) gx = cap;
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }
 
-template <int PH, int PW, int NT, bool STAMP>
+template <int PH, int PW, int NT, bool M16, bool STAMP>
 int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
-    if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, STAMP>(p, ntiles_n, s);
-    if (p.epi_add) return launch_patch<PH, PW, NT, true, false, STAMP>(p, ntiles_n, s);
-    if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, STAMP>(p, ntiles_n, s);
-    return launch_patch<PH, PW, NT, false, false, STAMP>(p, ntiles_n, s);
+    if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, M16, STAMP>(p, ntiles_n, s);
+    if (p.epi_add) return launch_patch<PH, PW, NT, true, false, M16, STAMP>(p, ntiles_n, s);
+    if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, M16, STAMP>(p, ntiles_n, s);
+    return launch_patch<PH, PW, NT, false, false, M16, STAMP>(p, ntiles_n, s);
 }
 
 }  // namespace
@@ -505,9 +559,9 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     *handled = true;
     const int ntn = g.CO / 128;
     if (g.stamps) {     // diagnostics build of the same kernel (scripts/patch_gemm_shares.py)
-        if (kind == 0) return launch_patch_epi<6, 34, 9, true>(p, ntn, s);
-        return launch_patch_epi<5, 33, 4, true>(p, ntn, s);
+        if (kind == 0) return launch_patch_epi<6, 34, 9, NSG_FRAG_M16 != 0, true>(p, ntn, s);
+        return launch_patch_epi<5, 33, 4, NSG_FRAG_M16 != 0, true>(p, ntn, s);
     }
-    if (kind == 0) return launch_patch_epi<6, 34, 9, false>(p, ntn, s);
-    return launch_patch_epi<5, 33, 4, false>(p, ntn, s);
+    if (kind == 0) return launch_patch_epi<6, 34, 9, NSG_FRAG_M16 != 0, false>(p, ntn, s);
+    return launch_patch_epi<5, 33, 4, NSG_FRAG_M16 != 0, false>(p, ntn, s);
 }

@@ -206,6 +206,21 @@ struct WgradParams {
 
 // A packed bf16 weight image [taps][NN][CC] is followed by its fragment-ordered twin (conv_api.hip: PackJob::frag) when:
 static inline bool nsg_frag_image(int NN, int CC) { return NN % 128 == 0 && CC % 64 == 0; }
+// Order of that twin = the MFMA shape gemm_patch.hip is built for (one build-time choice shared with conv_api.hip's pack kernel):
+//   0: v_mfma_f32_32x32x16_bf16  [t][c/64][n/32][(c%64)/16][lane = n%32 + 32*((c%16)/8)][c%8]
+//   1: v_mfma_f32_16x16x32_bf16  [t][c/64][n/32][(n%32)/16][(c%64)/32][lane = n%16 + 16*((c%32)/8)][c%8]
+#ifndef NSG_FRAG_M16
+#define NSG_FRAG_M16 0   /* measured in the step (B = 128, D = 128): 946 TF (32x32x16) vs 955-961 TF (16x16x32): within noise -- not MFMA-clock-bound */
+#endif
+__host__ __device__ static inline int64_t nsg_frag_index(int t, int n, int c, int NN, int CC)
+{
+    const int64_t blk = ((int64_t)(t * (CC >> 6) + (c >> 6)) * (NN >> 5) + (n >> 5)) * 4;
+#if NSG_FRAG_M16
+    return ((blk + 2 * ((n & 31) >> 4) + ((c & 63) >> 5)) * 64 + (n & 15) + 16 * ((c & 31) >> 3)) * 8 + (c & 7);
+#else
+    return ((blk + ((c & 63) >> 4)) * 64 + (n & 31) + 32 * ((c & 15) >> 3)) * 8 + (c & 7);
+#endif
+}
 int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
 // gemm_patch.hip: the patch-staged bf16 kernel for the shapes it implements (3x3/1, 4x4/2 and the transposed 4/2/1 with
 // C_in % 64 == 0, C_out % 128 == 0, bf16 in and out); p must have in_bytes / w_bytes filled in.  *handled = false -> not run.
