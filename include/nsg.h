@@ -161,7 +161,10 @@ NSG_API int nsg_vq_ema_update(float *e, float *ema_n, float *ema_s, const float 
 
 /* ELEMENTS (of d->dtype) to allocate for each packed weight image (forward image, dgrad image).
  * (The two single-channel layers keep one of their images as fp32 [C][16] for the stencil kernels whatever
- * d->dtype is; the count accounts for that.) */
+ * d->dtype is; bf16 layers whose channel counts the patch-staged kernel takes -- a multiple of 128 on one side and of
+ * 64 on the other -- carry a second, fragment-ordered copy behind the plain [tap][n][c] image, which the bf16 conv
+ * forward / data gradient reads: the count accounts for both.  Packed images are only ever produced by
+ * nsg_pack_conv_weights(_batch) into buffers of exactly this size.) */
 NSG_API size_t nsg_packed_weight_floats(const nsg_conv_desc *d);
 
 /* Re-pack reference-layout weights into the two [tap][n][c] images the GEMM kernels stream:
