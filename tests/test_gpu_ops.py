@@ -251,6 +251,8 @@ CONV_CASES = [
     (1, 20, 64, 128, 128, 3, 1, 1, False, True, False), # 128 channels (full)
     (1, 8, 16, 256, 256, 4, 2, 1, False, False, False), # 256 channels: two column tiles
     (1, 4, 8, 256, 256, 4, 2, 1, True, False, False),
+    (2, 20, 70, 128, 128, 3, 1, 1, False, False, False),  # 128 channels, no fused ReLU: the row-strip weight gradient (64-pixel strips + a ragged one)
+    (2, 14, 40, 128, 128, 4, 2, 1, False, False, False),  # ... its stride-2 form (32-pixel strips in fp32)
     (2, 9, 9, 96, 96, 3, 1, 1, False, False, False),    # channel count not a power of two
     (2, 12, 20, 16, 32, 7, 1, 3, False, False, False),  # 7x7 'same' (the PixelCNN prior's first layer, models.py:291)
     (1, 9, 11, 8, 8, 5, 1, 2, False, False, False),     # 5x5
