@@ -140,7 +140,7 @@ def load():
     # experiment switches (diagnostics): NSG_GATHER_DMA=0|1, NSG_GATHER_TILE8=0|1 select gather_gemm staging / tile variants
     for env, sym in (("NSG_GATHER_DMA", "nsg_debug_set_gather_dma"), ("NSG_GATHER_TILE8", "nsg_debug_set_gather_tile8"),
                      ("NSG_PATCH_GEMM", "nsg_debug_set_patch_gemm"), ("NSG_PATCH_GRID", "nsg_debug_set_patch_grid"),
-                     ("NSG_WGRAD_STRIP", "nsg_debug_set_wgrad_strip")):
+                     ("NSG_WGRAD_STRIP", "nsg_debug_set_wgrad_strip"), ("NSG_PATCH_DIRECT", "nsg_debug_set_patch_direct")):
         if env in os.environ:
             fn = getattr(lib, sym)
             fn.argtypes = [c_int32]

@@ -602,6 +602,10 @@ extern "C" NSG_API void nsg_debug_set_gather_dma(int on) { g_gather_dma = on; }
 
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 {
+    GatherGemmParams q = p;         // (the byte sizes only matter to the launch itself)
+    if (!q.stats) q.stats = reinterpret_cast<float *>(16);
+    const int rec = nsg_patch_gemm_stat_records(q);
+    if (rec > 0) return rec;        // gemm_patch.hip: one record per workgroup
     return (int)nsg_cdiv(p.M, 128) * (p.mode == 0 ? 1 : 4);
 }
 

@@ -29,7 +29,10 @@
 namespace {
 
 int g_patch_gemm = 1;        // nsg_debug_set_patch_gemm: 0 sends everything back to gemm_gather.hip's kernel (A/B runs)
+int g_patch_direct = 0;      // nsg_debug_set_patch_direct: the plain variant's epilogue straight from the accumulators (no LDS, no barrier).  Measured in the step: 3x3 forward 188-189 us vs 181-182 staged, transposed 405-408 vs 390-395: off
 int g_patch_grid_cap = 512;  // nsg_debug_set_patch_grid: workgroups per launch (2 per CU resident: each walks tiles with a grid stride); 0 = one tile each
+
+inline int patch_grid(int ntiles) { return (g_patch_grid_cap > 0 && ntiles > g_patch_grid_cap) ? g_patch_grid_cap : ntiles; }
 
 constexpr int PG_MAX_JOBS = 16;
 constexpr int PG_MAX_TAPS = 64;
@@ -62,6 +65,7 @@ struct PatchGemmParams {
     int flags;
     unsigned in_bytes, w_bytes;
     unsigned long long *stamps;     // diagnostics build only: [workgroup][8] cycle counts (never read by any kernel)
+    float *stats;                   // STATS builds: [gridDim.x][3][CO] (count, sum, M2 about the record's mean) of the stored output
     PatchJob jobs[PG_MAX_JOBS];
     PatchTap taps[PG_MAX_TAPS];
 };
@@ -70,7 +74,13 @@ struct PatchGemmParams {
 // compile-time (a run-time "maybe a load" makes hipcc guard every reuse of the destination registers with a conservative
 // vmcnt that also waits for the tile's own STORES -- the epilogue then runs at store-acknowledge latency); STAMP: diagnostics
 // M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same FLOP per cycle; the chip holds a higher clock on it)
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false>
+// STATS: the batch statistics of the BatchNorm that follows, from the store phase (one record per workgroup: a thread keeps
+// the same 8 channels for every piece it stores, so it carries their running sums across its tiles) instead of a pass over y
+// DIRECT (plain variant, 32x32x16 only): the epilogue goes straight from the accumulators to memory -- one v_permlane32_swap
+// per register gives a lane 8 consecutive channels of its pixel (16-byte stores in 32-byte segments; L2 merges the four waves'
+// quarters of a pixel row) -- no LDS staging, no barrier.  With fused operands their loads would be 32-byte segments too
+// (the vector L1's line rate again), so those variants keep the staged form.
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false, bool STATS = false, bool DIRECT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
@@ -139,6 +149,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
+    float st_sum[STATS ? 8 : 1], st_sq[STATS ? 8 : 1], st_pv[STATS ? 8 : 1], st_cnt = 0.f;   // sums of (y - pivot), (y - pivot)^2, the pivot (the thread's first value), the count
+#pragma unroll
+    for (int e = 0; e < (STATS ? 8 : 1); ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; st_pv[e] = 0.f; }
 
     // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
     // would share lgkmcnt with the fragment reads and drain them.
@@ -313,6 +326,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     auto flush = [&](int tile, const PatchJob &jb, int buf) __attribute__((always_inline)) {
         int b, ty, tx;
         tile_origin(tile, b, ty, tx);
+        if constexpr (DIRECT) {
+            static_assert(!DIRECT || (!ADD && !MASK && !M16 && !STATS), "the register epilogue is the plain 32x32x16 variant's");
+            // register group g of lane (x, h) of tile row y = channels 32 w + 8 g + 4 h .. + 3 of pixel (y, x); swapping the upper
+            // half of group g with the lower half of group g + 1 leaves lane (x, 0) with channels 8 g .. + 7 and lane (x, 1)
+            // with 8 (g + 1) .. + 7: 16 bytes of bf16 each.  Same arithmetic and order as the staged form.
+            float bvd[2][8];
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bvd[gp][e] = p.bias ? p.bias[n0 + 32 * wave + 16 * gp + 8 * h + e] : 0.f;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int oy = (ty * 4 + y) * p.os + jb.oy;
+                const int ox = (tx * 32 + x31) * p.os + jb.ox;
+                const unsigned pix = (oy < p.OH && ox < p.OW) ? (unsigned)(((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + 32 * wave + 8 * h) * 2u : OOB;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(nsg_fbits(acc[y][8 * gp + i]), nsg_fbits(acc[y][8 * gp + 4 + i]), false, false);
+                        v[i] = nsg_bitsf(sw[0]);
+                        v[4 + i] = nsg_bitsf(sw[1]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bvd[gp][e];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];
+                    unsigned u[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)(pix == OOB ? OOB : pix + 32u * gp), 0, 0);
+                }
+            }
+            return;
+        }
         float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
         // this thread's 8 output pieces: tile row y, pixel (tid >> 4) + 16 e2, channels 8 cg .. + 7
         unsigned off[4][2];     // BYTE offsets; OOB for pixels outside the image
@@ -374,6 +424,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
                 unsigned u[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
+                if constexpr (STATS) {      // one pass about a pivot, of the values AS STORED (rounded to bf16), real pixels only
+                    const float live = off[y][e2] != OOB ? 1.f : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float y0 = nsg_bitsf(u[i] << 16), y1 = nsg_bitsf(u[i] & 0xffff0000u);
+                        st_pv[2 * i] = (st_cnt == 0.f) ? y0 : st_pv[2 * i];
+                        st_pv[2 * i + 1] = (st_cnt == 0.f) ? y1 : st_pv[2 * i + 1];
+                        const float d0 = (y0 - st_pv[2 * i]) * live, d1 = (y1 - st_pv[2 * i + 1]) * live;
+                        st_sum[2 * i] += d0;
+                        st_sum[2 * i + 1] += d1;
+                        st_sq[2 * i] = __builtin_fmaf(d0, d0, st_sq[2 * i]);
+                        st_sq[2 * i + 1] = __builtin_fmaf(d1, d1, st_sq[2 * i + 1]);
+                    }
+                    st_cnt += live;
+                }
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)off[y][e2], 0, 0);
             }
@@ -441,6 +506,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             do_job(std::integral_constant<int, 1>{});
         }
     }
+    if constexpr (STATS) {
+        // (count, mean, M2) of each thread, pooled over the 16 threads of its channel group in thread order (double): one record
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);      // [17][256]: 8 means, 8 M2s, the count
+        const float inv = st_cnt > 0.f ? 1.f / st_cnt : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[e * 256 + tid] = st_pv[e] + st_sum[e] * inv;
+            red[(8 + e) * 256 + tid] = fmaxf(st_sq[e] - st_sum[e] * st_sum[e] * inv, 0.f);
+        }
+        red[16 * 256 + tid] = st_cnt;
+        __syncthreads();
+        if (tid < 128) {
+            const int grp = tid >> 3, e = tid & 7;
+            double N = 0.0, S = 0.0;
+            for (int r = 0; r < 16; ++r) {
+                const double n = red[16 * 256 + r * 16 + grp];
+                N += n;
+                S += n * (double)red[e * 256 + r * 16 + grp];
+            }
+            const double mu = N > 0.0 ? S / N : 0.0;
+            double Q = 0.0;
+            for (int r = 0; r < 16; ++r) {
+                const double n = red[16 * 256 + r * 16 + grp];
+                const double dl = (double)red[e * 256 + r * 16 + grp] - mu;
+                Q += n > 0.0 ? (double)red[(8 + e) * 256 + r * 16 + grp] + n * dl * dl : 0.0;
+            }
+            float *dst = p.stats + (size_t)blockIdx.x * 3 * p.CO + n0 + tid;
+            dst[0] = (float)N;
+            dst[p.CO] = (float)S;
+            dst[2 * p.CO] = (float)Q;
+        }
+    }
     if constexpr (STAMP) {
         if (tid == 0 && p.stamps) {
             unsigned long long *o = p.stamps + 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
@@ -450,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
 }
 
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false>
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false, bool STATS = false, bool DIRECT = false>
 int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
@@ -458,23 +556,27 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
     const size_t lds = 2 * BUF_BYTES;
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP, STATS, DIRECT>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
-    int gx = p.ntiles;
-    const int cap = g_patch_grid_cap > 0 ? g_patch_grid_cap : 0;
-    if (cap > 0 && gx > cap) gx = cap;
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    const int gx = patch_grid(p.ntiles);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP, STATS, DIRECT>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }
 
 template <int PH, int PW, int NT, bool M16, bool STAMP>
 int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
+    if constexpr (!STAMP) {
+        if (p.stats) return launch_patch<PH, PW, NT, false, false, M16, false, true>(p, ntiles_n, s);
+    }
     if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, M16, STAMP>(p, ntiles_n, s);
     if (p.epi_add) return launch_patch<PH, PW, NT, true, false, M16, STAMP>(p, ntiles_n, s);
     if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, M16, STAMP>(p, ntiles_n, s);
+    if constexpr (!M16) {
+        if (g_patch_direct) return launch_patch<PH, PW, NT, false, false, M16, STAMP, false, true>(p, ntiles_n, s);
+    }
     return launch_patch<PH, PW, NT, false, false, M16, STAMP>(p, ntiles_n, s);
 }
 
@@ -482,24 +584,45 @@ int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 
 extern "C" NSG_API void nsg_debug_set_patch_gemm(int on) { g_patch_gemm = on; }
 extern "C" NSG_API void nsg_debug_set_patch_grid(int cap) { g_patch_grid_cap = cap; }
+extern "C" NSG_API void nsg_debug_set_patch_direct(int on) { g_patch_direct = on; }
+
+// kind of the launch for this file (0: 3x3 stride 1, 1: 4x4 stride 2 pad 1, 2: transposed 4/2/1), or -1: not taken
+static int patch_kind(const GatherGemmParams &g)
+{
+    if (!g_patch_gemm) return -1;
+    if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return -1;
+    if (g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) return -1;
+    if (g.stats && (g.epi_add || g.epi_mask || (g.flags & NSG_RELU_OUT) || g.stamps)) return -1;
+    if (g.CI % 64 != 0 || g.CO % 128 != 0) return -1;
+    const int chunks = g.CI / 64;
+    int kind;
+    if (g.mode == 1) kind = 2;
+    else if (g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad >= 0 && g.pad <= 2 && g.pad_w >= 0 && g.pad_w <= 2) kind = 0;
+    else if (g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 1 && g.pad_w == 1) kind = 1;
+    else return -1;
+    const int njobs = kind == 0 ? chunks : 4 * chunks;
+    const int ntaps = kind == 0 ? 9 : 4;
+    if (njobs > PG_MAX_JOBS || njobs * ntaps > PG_MAX_TAPS) return -1;
+    if ((int64_t)g.B * nsg_cdiv(g.RH, 4) * nsg_cdiv(g.RW, 32) > 0x3fffffff) return -1;
+    return kind;
+}
+
+// Statistics records a launch with these parameters writes when gemm_patch.hip runs it (one per workgroup), or 0 when it does not.
+int nsg_patch_gemm_stat_records(const GatherGemmParams &g)
+{
+    if (patch_kind(g) < 0) return 0;
+    return patch_grid((int)((int64_t)g.B * nsg_cdiv(g.RH, 4) * nsg_cdiv(g.RW, 32)));
+}
 
 // Runs the launch on the patch-staged kernel when its shape is one this file implements; *handled says whether it did.
 int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handled)
 {
     *handled = false;
-    if (!g_patch_gemm) return NSG_OK;
-    if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return NSG_OK;
-    if ((g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) || g.stats) return NSG_OK;
-    if (g.CI % 64 != 0 || g.CO % 128 != 0) return NSG_OK;
+    const int kind = patch_kind(g);
+    if (kind < 0) return NSG_OK;
     const int chunks = g.CI / 64;
-    int kind;    // 0: 3x3 stride 1, 1: 4x4 stride 2 pad 1, 2: transposed 4/2/1
-    if (g.mode == 1) kind = 2;
-    else if (g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad >= 0 && g.pad <= 2 && g.pad_w >= 0 && g.pad_w <= 2) kind = 0;
-    else if (g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 1 && g.pad_w == 1) kind = 1;
-    else return NSG_OK;
     const int njobs = kind == 0 ? chunks : 4 * chunks;
     const int ntaps = kind == 0 ? 9 : 4;
-    if (njobs > PG_MAX_JOBS || njobs * ntaps > PG_MAX_TAPS) return NSG_OK;
 
     PatchGemmParams p = {};
     p.in = reinterpret_cast<const bf16_t *>(g.in);
@@ -524,6 +647,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     p.flags = g.flags;
     p.in_bytes = g.in_bytes; p.w_bytes = g.w_bytes;
     p.stamps = g.stamps;
+    p.stats = g.stats;
     const int64_t blk = (int64_t)(g.CO / 32) * 4096;    // bytes of one (tap, 64-channel chunk) block of the fragment-ordered image
     auto wblock = [&](int ws, int c) { return (unsigned)(((int64_t)ws * chunks + c) * blk); };
     int j = 0;
