@@ -135,6 +135,14 @@ NSG_API int nsg_index_add_rows(const int64_t *idx, const float *g, int64_t N, in
 NSG_API int nsg_index_add_rows_bf16x2(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
                                       float *counts_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same sums as a sorted segment sum: a stable counting sort of the row INDICES by code, then every code's rows added in
+ * row order (fp32, bitwise reproducible).  Moves N*D*4 bytes instead of doing 2*N*K*D flops: the form for large codebooks
+ * (K = 8192) and the default of the training step.  Rows whose index lies outside [0, K) contribute nothing.
+ * Needs D % 4 == 0 with D / 4 a power of two up to 64 (or D a multiple of 256), K <= 8192, N < 2^31. */
+NSG_API size_t nsg_index_add_sorted_workspace_bytes(int64_t N, int32_t D, int32_t K);
+NSG_API int nsg_index_add_rows_sorted(const int64_t *idx, const float *g, int64_t N, int32_t D, int32_t K, float *out,
+                                      float *counts_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* out[i][:] = e[idx[i]][:] for i < N.  Replaces torch.index_select(codebook, 0, indices)
  * (vector_quantization.py:40-41, src/models.py:137) and self.codebook.embedding(latents)
  * (src/models.py:194).  Indices outside [0,K) are clamped. */

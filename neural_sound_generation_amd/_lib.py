@@ -46,6 +46,8 @@ _SIGS = {
     "nsg_index_add_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "nsg_index_add_rows": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "nsg_index_add_rows_bf16x2": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "nsg_index_add_sorted_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "nsg_index_add_rows_sorted": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "nsg_gather_rows": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P]),
     "nsg_vq_ema_update": (None, [_P, _P, _P, _P, _P, c_int32, c_int32, c_float, c_float, _P, _P]),
     "nsg_codebook_grad_from_sums": (None, [_P, _P, _P, c_int32, c_int32, c_float, _P, _P]),

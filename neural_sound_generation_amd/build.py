@@ -18,7 +18,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libnsg.so")
-SOURCES = ["api_common.hip", "gemm_gather.hip", "gemm_patch.hip", "gemm_wgrad.hip", "gemm_wgrad_strip.hip", "gemm_flat.hip", "vq.hip", "vq_bf16.hip", "bn.hip", "elementwise.hip", "conv_api.hip", "stencil_c1.hip", "c1_mfma.hip", "prior_ops.hip", "audio.hip", "diag.hip"]
+SOURCES = ["api_common.hip", "gemm_gather.hip", "gemm_patch.hip", "gemm_wgrad.hip", "gemm_wgrad_strip.hip", "gemm_flat.hip", "vq.hip", "segsum.hip", "vq_bf16.hip", "bn.hip", "elementwise.hip", "conv_api.hip", "stencil_c1.hip", "c1_mfma.hip", "prior_ops.hip", "audio.hip", "diag.hip"]
 # -ffp-contract=off: the bit-exact VQ path spells out every fma itself; nothing may be re-fused.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -171,9 +171,16 @@ def rowsumsq(v):
     return out
 
 
+def index_add_sorted_supported(N, D, K) -> bool:
+    """Shapes nsg_index_add_rows_sorted takes (include/nsg.h)."""
+    ppr = D // 4
+    return D % 4 == 0 and K <= 8192 and N < 2 ** 31 and (ppr > 64 and D % 256 == 0 or ppr <= 64 and ppr & (ppr - 1) == 0)
+
+
 def index_add_rows(idx, g2d, K, want_counts=False, impl="f32", out=None, counts=None):
-    """out[k] = sum of rows of g2d whose idx == k; deterministic.  impl: "f32" (fp32 matrix pipe, exact products) or
-    "bf16x2" (the bf16 compute mode: rows split into bf16 hi + lo, relative error of a sum ~2^-17).
+    """out[k] = sum of rows of g2d whose idx == k; deterministic.  impl: "sorted" (a sorted segment sum in fp32: N*D*4 bytes
+    moved; the training step's default), "f32" (one-hot GEMM on the fp32 matrix pipe, exact products) or "bf16x2" (one-hot GEMM
+    on the bf16 pipe: rows split into bf16 hi + lo, relative error of a sum ~2^-17).
     out (K, D) / counts (K,): optional preallocated fp32 destinations (e.g. views of a communication buffer)."""
     _chk(idx, "idx", torch.int64); _chk(g2d, "g")
     N, D = g2d.shape
@@ -187,6 +194,20 @@ def index_add_rows(idx, g2d, K, want_counts=False, impl="f32", out=None, counts=
         want_counts = True
     elif want_counts:
         counts = torch.empty(K, dtype=torch.float32, device=g2d.device)
+    if impl == "sorted" and not index_add_sorted_supported(N, D, K):
+        impl = "f32"
+    if impl == "sorted":
+        if N == 0:
+            out.zero_()
+            if counts is not None:
+                counts.zero_()
+            return (out, counts) if want_counts else out
+        nb = _lib.query("nsg_index_add_sorted_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
+        ws = WS.get(nb, g2d.device)
+        _lib.tag("index_add_rows (sorted segment sum)", 0, 4.0 * N * D + 8.0 * N)
+        _lib.call("nsg_index_add_rows_sorted", _p(idx), _p(g2d), c_int64(N), c_int32(D), c_int32(K), _p(out), _p(counts), _p(ws), c_size_t(nb),
+                  _stream())
+        return (out, counts) if want_counts else out
     nb = _lib.query("nsg_index_add_workspace_bytes", c_int64(N), c_int32(D), c_int32(K))
     ws = WS.get(nb, g2d.device)
     _lib.tag("index_add_rows (one-hot GEMM, %s)" % impl, 2.0 * N * K * D, 4.0 * N * D + 8.0 * N)

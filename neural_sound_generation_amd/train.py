@@ -50,8 +50,12 @@ class FusedTrainStep:
             tail = self.opt.reserve_tail(self._n_pad + K * D)
             self.ema_n = tail[:K]
             self.ema_s = tail[self._n_pad:].view(K, D)
-        # bf16 mode: the codebook scatter-add on the bf16 matrix pipe (rows split hi + lo); fp32 mode: exact products
-        self.scatter_impl = "bf16x2" if self.dtype == torch.bfloat16 else "f32"
+        # the codebook scatter-add as a sorted segment sum (fp32, deterministic; NSG_SCATTER_IMPL=onehot restores the one-hot
+        # GEMMs: bf16x2 on the bf16 pipe in the bf16 mode, exact fp32 products in the fp32 mode)
+        if os.environ.get("NSG_SCATTER_IMPL", "sorted") == "sorted":
+            self.scatter_impl = "sorted"
+        else:
+            self.scatter_impl = "bf16x2" if self.dtype == torch.bfloat16 else "f32"
         self.encP = engine.encoder_params(model.encoder)
         self.decP = engine.decoder_params(model.decoder)
         self.codebook = model.codebook.embedding.weight

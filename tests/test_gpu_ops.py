@@ -194,18 +194,41 @@ def test_vq_operator_surface(golden_dir):
     np.testing.assert_allclose(e2.grad.cpu().numpy(), g["st.ge"], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("N,D,K", [(300, 16, 24), (5000, 64, 128), (20000, 128, 512), (3000, 256, 1000), (4, 16, 7), (1000, 32, 101)])
-def test_index_add_rows_and_counts(N, D, K):
+@pytest.mark.parametrize("impl", ["f32", "sorted"])
+@pytest.mark.parametrize("N,D,K", [(300, 16, 24), (5000, 64, 128), (20000, 128, 512), (3000, 256, 1000), (4, 16, 7), (1000, 32, 101),
+                                   (9000, 256, 8192), (70000, 128, 512), (4097, 8, 3), (130, 512, 40)])
+def test_index_add_rows_and_counts(N, D, K, impl):
+    """index_add_ (vector_quantization.py:60-61): the one-hot GEMM and the sorted segment sum (stable counting sort of the row
+    indices, each code's rows added in row order).  Skewed (a third of the rows on one code: many sort rounds per 64 rows, many
+    128-row chunks per code), codes without rows, block boundaries of the sort (4096 rows), wide rows (D = 512)."""
     g = torch.Generator().manual_seed(N)
     idx = torch.randint(0, K, (N,), generator=g)
-    idx[: N // 3] = 5  # skewed: one hot code
+    idx[: N // 3] = min(5, K - 1)  # skewed: one hot code
     v = torch.randn(N, D, generator=g)
     want = torch.zeros(K, D, dtype=torch.float64).index_add_(0, idx, v.double())
-    out, cnt = ops.index_add_rows(gpu(idx), gpu(v), K, want_counts=True)
-    out2 = ops.index_add_rows(gpu(idx), gpu(v), K)
+    assert impl != "sorted" or ops.index_add_sorted_supported(N, D, K)
+    out, cnt = ops.index_add_rows(gpu(idx), gpu(v), K, want_counts=True, impl=impl)
+    out2 = ops.index_add_rows(gpu(idx), gpu(v), K, impl=impl)
     assert torch.equal(out, out2), "index_add_rows must be bitwise reproducible"
-    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-4)
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-6 * scale + 1e-6)
     assert torch.equal(cnt.cpu(), torch.bincount(idx, minlength=K).float())
+    if impl == "sorted":        # preallocated destinations (the EMA statistics live behind the gradient bucket), and sum order = row order:
+        kp = (K + 63) // 64 * 64                            # (16-byte aligned views, as FusedTrainStep lays them out)
+        buf = torch.full((kp + K * D,), float("nan"), device=DEV)
+        ops.index_add_rows(gpu(idx), gpu(v), K, impl=impl, out=buf[kp:].view(K, D), counts=buf[:K])
+        assert torch.equal(buf[kp:].view(K, D), out) and torch.equal(buf[:K], cnt)
+        k = int(idx[-1])                                    # a sparse code: its rows added one by one in row order, exactly
+        rows = (idx == k).nonzero().flatten()
+        if rows.numel() <= 128 and D <= 256:
+            acc = torch.zeros(D)
+            ppr, rpi = D // 4, max(1, 64 // (D // 4))
+            subs = [torch.zeros(D) for _ in range(rpi)]     # the kernel's lanes: row j of the chunk goes to sub-accumulator j % rpi
+            for j, r in enumerate(rows.tolist()):
+                subs[j % rpi] = subs[j % rpi] + v[r]
+            for sacc in subs:
+                acc = acc + sacc if sacc is not subs[0] else sacc.clone()
+            assert torch.equal(out[k].cpu(), acc), "a code's rows are summed in row order"
 
 
 def test_ema_update_against_oracle():
