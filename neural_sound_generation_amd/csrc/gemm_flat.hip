@@ -65,11 +65,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
     const int l31 = lane & 31, hb = lane >> 5;
 
     // ---- weights -> LDS as bf16 [n][k]: FWD n = out channel, k = in channel (w[n][k]); BWD n = in channel, k = out channel (w[k][n]) ----
-    for (int i = tid; i < C * C / 2; i += 256) {
-        const int n = i / (C / 2), k = (i - n * (C / 2)) * 2;
-        const float a = MODE == 0 ? p.w[(size_t)n * C + k] : p.w[(size_t)k * C + n];
-        const float b = MODE == 0 ? p.w[(size_t)n * C + k + 1] : p.w[(size_t)(k + 1) * C + n];
-        *reinterpret_cast<unsigned *>(wt + n * PITCH + k) = pack_bf16(a, b);
+    // (all the loads first, then the conversions: a rolled loop waits for every load in turn, 32 L2 round trips per block)
+    constexpr int WIT = C * C / 2 / 256;
+    {
+        float wa[WIT], wb[WIT];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + 256 * it;                       // FWD: lanes along k (a row of w);  BWD: lanes along n (rows k, k + 1 of w)
+            const int n = MODE == 0 ? i / (C / 2) : i % C, k = MODE == 0 ? (i - n * (C / 2)) * 2 : (i / C) * 2;
+            wa[it] = MODE == 0 ? p.w[(size_t)n * C + k] : p.w[(size_t)k * C + n];
+            wb[it] = MODE == 0 ? p.w[(size_t)n * C + k + 1] : p.w[(size_t)(k + 1) * C + n];
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + 256 * it;
+            const int n = MODE == 0 ? i / (C / 2) : i % C, k = MODE == 0 ? (i - n * (C / 2)) * 2 : (i / C) * 2;
+            *reinterpret_cast<unsigned *>(wt + n * PITCH + k) = pack_bf16(wa[it], wb[it]);
+        }
     }
     if (tid < C) sbias[tid] = (MODE == 0 && p.bias) ? p.bias[tid] : 0.f;
     // ---- this thread's staging pieces: piece i = (row tid / CPR + (256 / CPR) i, channels cc8 .. cc8+7), the SAME channels for every piece ----
@@ -77,6 +89,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
     constexpr int RSTEP = 256 / CPR;
     // per-channel constants of the staging transform.  FWD: k0 = fs = invstd*gamma, k1 = off = beta - mean*fs.
     // BWD: k0 = sc = gamma*invstd, k1 = sc*invstd*dgamma/M, k2 = sc*dbeta/M - k1*mean  (dh = sc*dy - (k1*h + k2))
+    // (BWD keeps them in LDS and reads them at the start of the phase that uses them: the kernel sits at the 256-register limit)
+    __shared__ __attribute__((aligned(16))) float sconst[MODE == 1 ? 6 * C : 4];
     float k0[8], k1[8], k2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -103,9 +117,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
         pbe[e] = prev ? p.prev_beta[cc8 + e] : 0.f;
         ps1[e] = 0.f; ps2[e] = 0.f;
     }
+    if (MODE == 1 && prow == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sconst[cc8 + e] = k0[e]; sconst[C + cc8 + e] = k1[e]; sconst[2 * C + cc8 + e] = k2[e];
+            sconst[3 * C + cc8 + e] = pmu[e]; sconst[4 * C + cc8 + e] = pfs[e]; sconst[5 * C + cc8 + e] = pbe[e];
+        }
+    }
+    if (MODE == 1) __syncthreads();
+    auto consts = [&](int j, float (&v)[8]) __attribute__((always_inline)) {
+        const v4f a = *reinterpret_cast<const v4f *>(sconst + j * C + cc8), b = *reinterpret_cast<const v4f *>(sconst + j * C + cc8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    };
     const int64_t ntiles = (p.M + ROWS - 1) / ROWS;
-    v4f px[PIECES], pg[MODE == 1 ? PIECES : 1];
-    auto prefetch = [&](int64_t t) {
+    // FWD keeps TWO tiles of loads in flight (register sets px and py, used alternately); BWD one (it also carries dy and prev_x)
+    v4f px[PIECES], py[MODE == 0 ? PIECES : 1], pg[MODE == 1 ? PIECES : 1];
+    auto prefetch = [&](int64_t t, v4f (&px)[PIECES]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int64_t m = t * ROWS + prow + RSTEP * i;
@@ -114,7 +141,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
             if (MODE == 1) pg[i] = *reinterpret_cast<const v4f *>(p.g + off);
         }
     };
-    auto stage = [&](int64_t t) {       // registers -> transform -> LDS tile (and, backward, dh -> global)
+    auto stage = [&](int64_t t, v4f (&px)[PIECES]) __attribute__((always_inline)) {       // registers -> transform -> LDS tile (and, backward, dh -> global)
+        if (MODE == 1) { consts(0, k0); consts(1, k1); consts(2, k2); }
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int row = prow + RSTEP * i;
@@ -140,11 +168,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
         }
     };
 
-    if ((int64_t)blockIdx.x < ntiles) { prefetch(blockIdx.x); stage(blockIdx.x); }
+    const int64_t G = gridDim.x;
+    if ((int64_t)blockIdx.x < ntiles) { prefetch(blockIdx.x, px); stage(blockIdx.x, px); }
+    if constexpr (MODE == 0) {      // (rows past the end are clamped, so these loads and the staging below need no conditions: no branches
+        prefetch(blockIdx.x + G, px);                      // between a load and its use, which hipcc answers with s_waitcnt vmcnt(0))
+        prefetch(blockIdx.x + 2 * G, py);
+    }
     __syncthreads();
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t nxt = t + gridDim.x;
-        if (nxt < ntiles) prefetch(nxt);
+    auto one_tile = [&](int64_t t, v4f (&pn)[PIECES]) __attribute__((always_inline)) {     // pn: FWD the set holding tile t + G
+        const int64_t nxt = t + G;
+        if (MODE == 1 && nxt < ntiles) prefetch(nxt, pn);
         v4f ph[MODE == 1 ? PIECES : 1];
         if (prev) {                            // the rows of prev_x under THIS tile: in flight across the MFMA loop, used in the store phase
 #pragma unroll
@@ -182,6 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
                 *reinterpret_cast<v2u *>(orow + ch) = pk;
             }
         __syncthreads();                       // the output tile is complete
+        if (prev) { consts(3, pmu); consts(4, pfs); consts(5, pbe); }
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int row = prow + RSTEP * i;
@@ -216,8 +250,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
             }
         }
         __syncthreads();                       // ... and has left LDS
-        if (nxt < ntiles) stage(nxt);
+        if (MODE == 0) {
+            stage(nxt, pn);
+            prefetch(t + 3 * G, pn);
+        } else if (nxt < ntiles) {
+            stage(nxt, pn);
+        }
         __syncthreads();
+    };
+    if constexpr (MODE == 0) {
+        for (int64_t t = blockIdx.x; t < ntiles; t += 2 * G) {
+            one_tile(t, px);
+            if (t + G < ntiles) one_tile(t + G, py);
+        }
+    } else {
+        for (int64_t t = blockIdx.x; t < ntiles; t += G) one_tile(t, px);
     }
     if (MODE == 0 && p.stat_tiles) {
         // (count, mean, M2) of each thread, pooled over the 256 / CPR threads of its channel group in row-slot order (double)
@@ -305,7 +352,7 @@ int dispatch_flat(const FlatParams &p, int C, int blocks, hipStream_t s)
     }
 }
 
-constexpr int FLAT_BLOCKS = 1024;
+constexpr int FLAT_BLOCKS = 512;      // 2 blocks per CU are resident (LDS): one prologue per block slot
 
 }  // namespace
 
