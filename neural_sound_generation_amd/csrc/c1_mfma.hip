@@ -528,8 +528,9 @@ __global__ __launch_bounds__(256) void bnrelu_dots_kernel(const bf16_t *__restri
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c0 = 16 * ks + 8 * hb + 2 * i;
-            wa[ks][i] = n < 16 ? pack_bf16(w[(size_t)c0 * 16 + n], w[(size_t)(c0 + 1) * 16 + n]) : 0u;
+            const int c0 = 16 * ks + 8 * hb + 2 * i;       // (unconditional loads, then the select: a load under a lane condition
+            const unsigned pk = pack_bf16(w[(size_t)c0 * 16 + (n & 15)], w[(size_t)(c0 + 1) * 16 + (n & 15)]);   // gets its own branch
+            wa[ks][i] = n < 16 ? pk : 0u;                  // and s_waitcnt vmcnt(0): 4 KS memory round trips in a row)
         }
     const int64_t ntiles = (M + ROWS - 1) / ROWS;
     v4f pr[PIECES];
@@ -590,13 +591,14 @@ __global__ __launch_bounds__(256) void bnrelu_dots_kernel(const bf16_t *__restri
 }  // namespace
 
 // ---- launchers (stencil_c1.hip's C ABI picks these for bf16 tensors with C = 32, 64, 96 or 128) ----
-bool nsg_c1m_supported(int C) { return C % 32 == 0 && C >= 32 && C <= 128; }
+bool nsg_c1m_supported(int C) { return (C % 32 == 0 && C >= 32 && C <= 128) || C == 256; }
 
 #define NSG_C1M_DISPATCH(KERNEL, ...)                                                                                   \
     switch (C / 32) {                                                                                                   \
     case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(blocks), dim3(64), 0, s, __VA_ARGS__); break;                          \
     case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(blocks), dim3(128), 0, s, __VA_ARGS__); break;                         \
     case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(blocks), dim3(192), 0, s, __VA_ARGS__); break;                         \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(blocks), dim3(512), 0, s, __VA_ARGS__); break;                         \
     default: hipLaunchKernelGGL((KERNEL<4>), dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;                        \
     }
 
@@ -605,6 +607,7 @@ bool nsg_c1m_supported(int C) { return C % 32 == 0 && C >= 32 && C <= 128; }
     case 1: hipLaunchKernelGGL((KERNEL<1, FLAG>), dim3(blocks), dim3(64), 0, s, __VA_ARGS__); break;                    \
     case 2: hipLaunchKernelGGL((KERNEL<2, FLAG>), dim3(blocks), dim3(128), 0, s, __VA_ARGS__); break;                   \
     case 3: hipLaunchKernelGGL((KERNEL<3, FLAG>), dim3(blocks), dim3(192), 0, s, __VA_ARGS__); break;                   \
+    case 8: hipLaunchKernelGGL((KERNEL<8, FLAG>), dim3(blocks), dim3(512), 0, s, __VA_ARGS__); break;                   \
     default: hipLaunchKernelGGL((KERNEL<4, FLAG>), dim3(blocks), dim3(256), 0, s, __VA_ARGS__); break;                  \
     }
 
@@ -648,13 +651,15 @@ int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd
                            float *dots, int64_t M, int C, hipStream_t s)
 {
     int64_t blocks = (M + 127) / 128;
-    if (blocks > 2048) blocks = 2048;
+    const int64_t cap = C > 128 ? 512 : 1024;      // the blocks resident at once (LDS): every block pays the weight prologue once
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) return NSG_OK;
     const bf16_t *ub = reinterpret_cast<const bf16_t *>(u);
     switch (C / 32) {
     case 1: hipLaunchKernelGGL((bnrelu_dots_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
     case 2: hipLaunchKernelGGL((bnrelu_dots_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
     case 3: hipLaunchKernelGGL((bnrelu_dots_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
+    case 8: hipLaunchKernelGGL((bnrelu_dots_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
     default: hipLaunchKernelGGL((bnrelu_dots_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, ub, mean, invstd, gamma, beta, w, dots, M); break;
     }
     return nsg_check_launch("bnrelu_dots_kernel");

@@ -666,7 +666,7 @@ size_t nsg_bn_relu_conv1x1_workspace_bytes(int64_t M, int32_t C)
 namespace {
 int check_1x1(const char *fn, int64_t M, int C, int dtype, size_t ws_bytes, const void *ws)
 {
-    if (!nsg_flat1x1_supported(dtype, C)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: needs bf16 tensors and C = 32, 64 or 128 (use the separate operators otherwise)", fn);
+    if (!nsg_flat1x1_supported(dtype, C)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: needs bf16 tensors and C = 32, 64, 128 or 256 (use the separate operators otherwise)", fn);
     if (M <= 0 || M >= 0x7fffffffLL / C) return nsg_fail(NSG_E_UNSUPPORTED, "%s: M = %lld rows not supported", fn, (long long)M);
     if (!ws || ws_bytes < nsg_bn_relu_conv1x1_workspace_bytes(M, C)) return nsg_fail(NSG_E_WORKSPACE, "%s: workspace too small", fn);
     return NSG_OK;

@@ -327,6 +327,307 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// C = 256 (BASELINE configs[3]).  The [256][256] bf16 weights are 128 KB: next to a row tile they do not fit in LDS, but they
+// fit in REGISTERS -- 8 waves, wave w keeps the 32 output channels 32w .. 32w+31 (all 256 k: 16 fragments = 64 VGPRs) for the
+// whole persistent block and multiplies them with EVERY row of the tile.  LDS holds only rows: two input tiles of 64 rows
+// (the next one is staged while this one is multiplied) and one output tile; 2 barriers per tile.  1 block of 512 threads
+// per CU; per tile 64 KB cross HBM, ~2 K clocks of MFMA per SIMD and ~2 K clocks of LDS reads against ~8 K clocks of HBM time.
+// Same arithmetic, rounding points and reduction shapes as flat_gemm_kernel (the staging transform, the bf16 store, the
+// per-thread pivot sums of the statistics), so the two give the same results where both apply.
+// ------------------------------------------------------------------------------------------------
+constexpr int WROWS = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void flat_wide_kernel(const FlatParams p)
+{
+    constexpr int C = 256, NT = 512, KS = C / 16, PITCH = C + 8, CPR = C / 8, RSTEP = NT / CPR, PIECES = WROWS / RSTEP;
+    static_assert(PIECES * RSTEP == WROWS, "whole pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *tin = reinterpret_cast<bf16_t *>(smem_raw);           // [2][WROWS][PITCH]
+    bf16_t *tout = tin + 2 * WROWS * PITCH;                       // [WROWS][PITCH]
+    __shared__ __attribute__((aligned(16))) float sconst[6 * C];  // FWD: fs, off;  BWD: sc, k1, k2, and the BatchNorm in front: mean, fs, beta
+    __shared__ __attribute__((aligned(16))) float sbias[C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hb = lane >> 5;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+    // ---- this wave's weights -> registers: A[n][k], n = 32 wave + l31, k = 16 ks + 8 hb .. +7.  FWD: A = w[n][k];  BWD: A = w[k][n] ----
+    bf16x8 wreg[KS];
+    {
+        const int n = 32 * wave + l31;
+        if (MODE == 0) {
+            v4f lo[KS], hi[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                lo[ks] = *reinterpret_cast<const v4f *>(p.w + (size_t)n * C + 16 * ks + 8 * hb);
+                hi[ks] = *reinterpret_cast<const v4f *>(p.w + (size_t)n * C + 16 * ks + 8 * hb + 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4u pk = {pack_bf16(lo[ks].x, lo[ks].y), pack_bf16(lo[ks].z, lo[ks].w), pack_bf16(hi[ks].x, hi[ks].y), pack_bf16(hi[ks].z, hi[ks].w)};
+                wreg[ks] = __builtin_bit_cast(bf16x8, pk);
+            }
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {      // (8 k-steps at a time: 64 loads in flight per lane)
+                float f[KS / 2][8];
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[ks][e] = p.w[(size_t)(16 * (ks + half * KS / 2) + 8 * hb + e) * C + n];
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks) {
+                    const v4u pk = {pack_bf16(f[ks][0], f[ks][1]), pack_bf16(f[ks][2], f[ks][3]), pack_bf16(f[ks][4], f[ks][5]), pack_bf16(f[ks][6], f[ks][7])};
+                    wreg[ks + half * KS / 2] = __builtin_bit_cast(bf16x8, pk);
+                }
+            }
+        }
+    }
+    // ---- per-channel constants of the staging transform and of the store phase -> LDS (read at the start of the phase using them) ----
+    const bool prev = MODE == 1 && p.prev_x != nullptr;
+    if (tid < C) {
+        const int c = tid;
+        if (MODE == 0) {
+            const float fs = p.invstd[c] * p.gamma[c];
+            sconst[c] = fs;
+            sconst[C + c] = __builtin_fmaf(-p.mean[c], fs, p.beta[c]);
+            sbias[c] = p.bias ? p.bias[c] : 0.f;
+        } else {
+            const float sc = p.gamma[c] * p.invstd[c];
+            const float k1 = sc * p.invstd[c] * (p.dgamma[c] * p.inv_m);
+            sconst[c] = sc;
+            sconst[C + c] = k1;
+            sconst[2 * C + c] = __builtin_fmaf(sc, p.dbeta[c] * p.inv_m, -(k1 * p.mean[c]));
+            sconst[3 * C + c] = prev ? p.prev_mean[c] : 0.f;
+            sconst[4 * C + c] = prev ? p.prev_invstd[c] * p.prev_gamma[c] : 0.f;
+            sconst[5 * C + c] = prev ? p.prev_beta[c] : 0.f;
+            sbias[c] = 0.f;
+        }
+    }
+    __syncthreads();
+    const int prow = tid / CPR, cc8 = (tid % CPR) * 8;
+    auto consts = [&](int j, float (&v)[8]) __attribute__((always_inline)) {
+        const v4f a = *reinterpret_cast<const v4f *>(sconst + j * C + cc8), b = *reinterpret_cast<const v4f *>(sconst + j * C + cc8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    };
+    float csum[8], ssq[8], spv[8], scnt = 0.f;     // BWD: column sums of dh.  FWD: sums of (y - pivot), (y - pivot)^2, the pivot, the count
+    float ps1[8], ps2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { csum[e] = 0.f; ssq[e] = 0.f; spv[e] = 0.f; ps1[e] = 0.f; ps2[e] = 0.f; }
+
+    const int64_t ntiles = (p.M + WROWS - 1) / WROWS;
+    const int64_t G = gridDim.x;
+    // stores through buffer descriptors: a row past the end gets an offset past the end and is dropped (no branch around a store)
+    constexpr unsigned OOB = 0xfffffff0u;
+    const unsigned nbytes = (unsigned)((size_t)p.M * C * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mid = __builtin_amdgcn_make_buffer_rsrc(MODE == 1 ? p.mid : p.out, 0, (int)nbytes, 0x00020000);
+
+    v4f px[PIECES], py[MODE == 0 ? PIECES : 1], pg[MODE == 1 ? PIECES : 1];
+    auto prefetch = [&](int64_t t, v4f (&px)[PIECES]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int64_t m = t * WROWS + prow + RSTEP * i;
+            const size_t off = (size_t)(m < p.M ? m : p.M - 1) * C + cc8;     // clamped: always inside the tensor
+            px[i] = *reinterpret_cast<const v4f *>(p.x + off);
+            if (MODE == 1) pg[i] = *reinterpret_cast<const v4f *>(p.g + off);
+        }
+    };
+    auto stage = [&](int64_t t, bf16_t *tile, v4f (&px)[PIECES]) __attribute__((always_inline)) {     // registers -> transform -> LDS (backward: dh -> global too)
+        float k0[8], k1[8], k2[8];
+        consts(0, k0); consts(1, k1);
+        if (MODE == 1) consts(2, k2);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = prow + RSTEP * i;
+            const int64_t m = t * WROWS + row;
+            float xv[8], o[8];
+            Elem<bf16_t>::unpack16(px[i], xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaxf(__builtin_fmaf(xv[e], k0[e], k1[e]), 0.f);
+            } else {
+                float gv[8];
+                Elem<bf16_t>::unpack16(pg[i], gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(k0[e], gv[e], -__builtin_fmaf(k1[e], xv[e], k2[e]));
+            }
+            const v4u pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+            *reinterpret_cast<v4u *>(tile + row * PITCH + cc8) = pk;
+            if (MODE == 1) {
+                const bool in = m < p.M;
+                __builtin_amdgcn_raw_buffer_store_b128(u4{pk.x, pk.y, pk.z, pk.w}, rs_mid, (int)(in ? (unsigned)(((size_t)m * C + cc8) * 2) : OOB), 0, 0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[e] += in ? o[e] : 0.f;
+            }
+        }
+    };
+
+    prefetch(blockIdx.x, px);
+    stage(blockIdx.x, tin, px);
+    if constexpr (MODE == 0) {
+        prefetch(blockIdx.x + G, px);
+        prefetch(blockIdx.x + 2 * G, py);
+    }
+    __syncthreads();
+    // pn: the register set the NEXT tile is staged from (FWD: it already holds tile t + G; BWD: loaded here)
+    auto one_tile = [&](int64_t t, int cur, v4f (&pn)[PIECES]) __attribute__((always_inline)) {
+        const int64_t nxt = t + G;
+        if (MODE == 1) prefetch(nxt, pn);
+        v4f ph[MODE == 1 ? PIECES : 1];
+        if (prev) {                            // the rows of prev_x under THIS tile: in flight across the MFMA loop, used in the store phase
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int64_t m = t * WROWS + prow + RSTEP * i;
+                ph[i] = *reinterpret_cast<const v4f *>(p.prev_x + (size_t)(m < p.M ? m : p.M - 1) * C + cc8);
+            }
+        }
+        const bf16_t *tile = tin + cur * WROWS * PITCH;
+        v16f acc[WROWS / 32];
+#pragma unroll
+        for (int rb = 0; rb < WROWS / 32; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        const bf16_t *brow = tile + l31 * PITCH + 8 * hb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < WROWS / 32; ++rb) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f *>(brow + 32 * rb * PITCH + 16 * ks));
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ks], b, acc[rb], 0, 0, 0);
+            }
+        // lane = row (32 rb + l31); registers 4q .. 4q+3 = channels 32 wave + 8 q + 4 hb .. +3
+#pragma unroll
+        for (int rb = 0; rb < WROWS / 32; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * wave + 8 * q + 4 * hb;
+                const v4f bv = *reinterpret_cast<const v4f *>(sbias + ch);
+                const v2u pk = {pack_bf16(acc[rb][4 * q] + bv.x, acc[rb][4 * q + 1] + bv.y), pack_bf16(acc[rb][4 * q + 2] + bv.z, acc[rb][4 * q + 3] + bv.w)};
+                *reinterpret_cast<v2u *>(tout + (32 * rb + l31) * PITCH + ch) = pk;
+            }
+        __syncthreads();                       // the output tile is complete (and every wave is done reading this input tile)
+        float pmu[8], pfs[8], pbe[8];
+        if (prev) { consts(3, pmu); consts(4, pfs); consts(5, pbe); }
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = prow + RSTEP * i;
+            const int64_t m = t * WROWS + row;
+            const bool in = m < p.M;
+            const v4f piece = *reinterpret_cast<const v4f *>(tout + row * PITCH + cc8);
+            const u4 pu = __builtin_bit_cast(u4, piece);
+            __builtin_amdgcn_raw_buffer_store_b128(pu, rs_out, (int)(in ? (unsigned)(((size_t)m * C + cc8) * 2) : OOB), 0, 0);
+            if (prev) {                    // bn_bwd_partial_kernel's sums on (prev_x, the dx values as stored), same mask expression
+                float dv[8], hv[8];
+                Elem<bf16_t>::unpack16(piece, dv);
+                Elem<bf16_t>::unpack16(ph[i], hv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float hc = hv[e] - pmu[e];
+                    const float ge = (in && (hc * pfs[e] + pbe[e]) > 0.f) ? dv[e] : 0.f;
+                    ps1[e] += ge;
+                    ps2[e] = __builtin_fmaf(ge, hc, ps2[e]);
+                }
+            }
+            if (MODE == 0 && p.stat_tiles && in) {          // one pass about a pivot (the thread's first value), of the values as stored
+                float yv[8];
+                Elem<bf16_t>::unpack16(piece, yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    spv[e] = scnt == 0.f ? yv[e] : spv[e];
+                    const float d = yv[e] - spv[e];
+                    csum[e] += d;
+                    ssq[e] = __builtin_fmaf(d, d, ssq[e]);
+                }
+                scnt += 1.f;
+            }
+        }
+        stage(nxt, tin + (cur ^ 1) * WROWS * PITCH, pn);       // (a tile past the end: clamped loads, dropped stores, zero sums)
+        if (MODE == 0) prefetch(t + 3 * G, pn);
+        __syncthreads();                       // the output tile has left LDS; the next input tile is in place
+    };
+    if constexpr (MODE == 0) {
+        for (int64_t t = blockIdx.x; t < ntiles; t += 2 * G) {
+            one_tile(t, 0, px);
+            if (t + G < ntiles) one_tile(t + G, 1, py);
+        }
+    } else {
+        int cur = 0;
+        for (int64_t t = blockIdx.x; t < ntiles; t += G, cur ^= 1) one_tile(t, cur, px);
+    }
+
+    // ---- closing reductions: threads with the same channel group (tid % CPR) are combined in row-slot order ----
+    float *red = reinterpret_cast<float *>(smem_raw);      // [17][NT] floats over the tiles (the loop ended on a barrier)
+    if (MODE == 0 && p.stat_tiles) {
+        const float inv = scnt > 0.f ? 1.f / scnt : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[e * NT + tid] = spv[e] + csum[e] * inv;
+            red[(8 + e) * NT + tid] = fmaxf(ssq[e] - csum[e] * csum[e] * inv, 0.f);
+        }
+        red[16 * NT + tid] = scnt;
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) {
+            const int grp = c >> 3, e = c & 7;
+            double N = 0.0, S = 0.0;
+            for (int r = 0; r < RSTEP; ++r) {
+                const double n = red[16 * NT + r * CPR + grp];
+                N += n;
+                S += n * (double)red[e * NT + r * CPR + grp];
+            }
+            const double mu = N > 0.0 ? S / N : 0.0;
+            double Q = 0.0;
+            for (int r = 0; r < RSTEP; ++r) {
+                const double n = red[16 * NT + r * CPR + grp];
+                const double dl = (double)red[e * NT + r * CPR + grp] - mu;
+                Q += n > 0.0 ? (double)red[(8 + e) * NT + r * CPR + grp] + n * dl * dl : 0.0;
+            }
+            float *dst = p.stat_tiles + (size_t)blockIdx.x * 3 * C;
+            dst[c] = (float)N;
+            dst[C + c] = (float)S;
+            dst[2 * C + c] = (float)Q;
+        }
+    }
+    if (prev) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[e * NT + tid] = ps1[e]; red[(8 + e) * NT + tid] = ps2[e]; }
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) {
+            const int grp = c >> 3, e = c & 7;
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RSTEP; ++r) { a += red[e * NT + r * CPR + grp]; b += red[(8 + e) * NT + r * CPR + grp]; }
+            p.prev_partial[(size_t)blockIdx.x * 2 * C + c] = a;
+            p.prev_partial[(size_t)blockIdx.x * 2 * C + C + c] = b * p.prev_invstd[c];
+        }
+        __syncthreads();
+    }
+    if (MODE == 1 && p.colsum_partial) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[e * NT + tid] = csum[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) {
+            const int grp = c >> 3, e = c & 7;
+            float sacc = 0.f;
+            for (int r = 0; r < RSTEP; ++r) sacc += red[e * NT + r * CPR + grp];
+            p.colsum_partial[(size_t)blockIdx.x * C + c] = sacc;
+        }
+    }
+}
+
+template <int MODE>
+int launch_flat_wide(const FlatParams &p, int blocks, hipStream_t s)
+{
+    constexpr int C = 256;
+    const size_t lds = (size_t)3 * WROWS * (C + 8) * sizeof(bf16_t);      // >= the [17][512] floats of the closing reductions
+    static_assert((size_t)3 * WROWS * (C + 8) * sizeof(bf16_t) >= (size_t)17 * 512 * sizeof(float), "closing reductions fit in the tiles");
+    static LdsOptIn once;
+    const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&flat_wide_kernel<MODE>)}, lds, "flat_gemm (C = 256)");
+    if (rc != NSG_OK) return rc;
+    hipLaunchKernelGGL((flat_wide_kernel<MODE>), dim3(blocks), dim3(512), lds, s, p);
+    return nsg_check_launch("flat_wide_kernel");
+}
+
 template <int NB, int MODE>
 int launch_flat(const FlatParams &p, int blocks, hipStream_t s)
 {
@@ -345,6 +646,7 @@ int launch_flat(const FlatParams &p, int blocks, hipStream_t s)
 template <int MODE>
 int dispatch_flat(const FlatParams &p, int C, int blocks, hipStream_t s)
 {
+    if (C == 256) return launch_flat_wide<MODE>(p, blocks, s);
     switch (C / 32) {
     case 1: return launch_flat<1, MODE>(p, blocks, s);
     case 2: return launch_flat<2, MODE>(p, blocks, s);
@@ -352,12 +654,20 @@ int dispatch_flat(const FlatParams &p, int C, int blocks, hipStream_t s)
     }
 }
 
+constexpr int FLAT_WIDE_BLOCKS = 256;  // C = 256: 1 block of 8 waves per CU
 constexpr int FLAT_BLOCKS = 512;      // 2 blocks per CU are resident (LDS): one prologue per block slot
+
+int flat_blocks(int64_t M, int C)
+{
+    const int rows = C == 256 ? WROWS : ROWS, cap = C == 256 ? FLAT_WIDE_BLOCKS : FLAT_BLOCKS;
+    const int64_t nt = (M + rows - 1) / rows;
+    return (int)(nt < cap ? nt : cap);
+}
 
 }  // namespace
 
 // (the staging keeps a thread on one channel group: 256 threads must be a whole number of tile rows, i.e. C / 8 divides 256)
-bool nsg_flat1x1_supported(int dtype, int C) { return dtype == NSG_BF16 && (C == 32 || C == 64 || C == 128); }
+bool nsg_flat1x1_supported(int dtype, int C) { return dtype == NSG_BF16 && (C == 32 || C == 64 || C == 128 || C == 256); }
 
 size_t nsg_flat1x1_workspace_bytes(int C)
 {
@@ -375,9 +685,9 @@ int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *in
     p.x = reinterpret_cast<const bf16_t *>(x); p.w = w; p.bias = bias; p.out = reinterpret_cast<bf16_t *>(y); p.M = M;
     p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
     p.stat_tiles = want_stats ? reinterpret_cast<float *>(ws) : nullptr;
-    const int64_t nt = (M + ROWS - 1) / ROWS;
-    const int blocks = (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS);
+    const int blocks = flat_blocks(M, C);
     if (nblocks) *nblocks = blocks;
+    if (C == 256 && !nsg_aligned16(w)) return nsg_fail(NSG_E_INVALID, "flat_gemm (C = 256): w must be 16-byte aligned");
     return dispatch_flat<0>(p, C, blocks, s);
 }
 
@@ -400,8 +710,7 @@ int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean
         if (prev_partial) *prev_partial = p.prev_partial;
     }
     p.out = reinterpret_cast<bf16_t *>(dx); p.mid = reinterpret_cast<bf16_t *>(dh); p.colsum_partial = partial; p.M = M;
-    const int64_t nt = (M + ROWS - 1) / ROWS;
-    const int blocks = (int)(nt < FLAT_BLOCKS ? nt : FLAT_BLOCKS);
+    const int blocks = flat_blocks(M, C);
     *nblocks = blocks;
     return dispatch_flat<1>(p, C, blocks, s);
 }
