@@ -54,6 +54,28 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
 {
     const PackJob j = jobs.job[blockIdx.y];
     const int64_t total = (int64_t)j.T * j.NN * j.CC;
+    if (j.bf16 && j.CC % 8 == 0 && (reinterpret_cast<uintptr_t>(j.dst) & 15u) == 0) {
+        // 8 consecutive c per thread: 8 independent (strided) reads in flight, one 16-byte store per image (8 consecutive c are
+        // contiguous in the fragment order too) instead of eight 2-byte ones
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const int CG = j.CC / 8;
+        for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total / 8; g += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)(g % CG) * 8;
+            const int n = (int)((g / CG) % j.NN);
+            const int t = (int)(g / ((int64_t)CG * j.NN));
+            const float *sp = j.src + (size_t)n * j.sn + (size_t)c * j.sc + (j.flip ? j.T - 1 - t : t);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = sp[(size_t)e * j.sc];
+            u4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (unsigned)nsg_f2bf(v[2 * e]) | ((unsigned)nsg_f2bf(v[2 * e + 1]) << 16);
+            bf16_t *d = reinterpret_cast<bf16_t *>(j.dst);
+            *reinterpret_cast<u4 *>(d + ((size_t)(t * j.NN + n) * j.CC + c)) = pk;
+            if (j.frag) *reinterpret_cast<u4 *>(d + total + nsg_frag_index(t, n, c, j.NN, j.CC)) = pk;
+        }
+        return;
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % j.CC);
         const int n = (int)((i / j.CC) % j.NN);
