@@ -6,18 +6,18 @@
 // and every code's rows are summed in that order, so the result is bitwise reproducible and only N*D*4 bytes move:
 //   A  seg_hist      per block of 1024 rows: LDS histogram of the codes                    -> blockcnt[b][k]
 //   B1 seg_scan_blk  per code: exclusive scan over blocks (in place), total[k]; counts[k]
-//   B2 seg_scan_code one block: base[k] = exclusive scan of total; chunks of <= 128 rows per code: chunkbase[k]
+//   B2 seg_scan_code one block: base[k] = exclusive scan of total; chunks of <= 512 rows per code: chunkbase[k]
 //   C  seg_place     one wave per block, 64 rows at a time in row order: position = running[k] + the row's rank among the 64
 //                    rows' lanes of its code, found through a lane mask per code built with LDS atomic ORs (order-independent)
 //                                                                                           -> perm[position] = row
-//   D  seg_sum       one wave per (code, chunk): fp32 sum of its rows in position order     -> partial[chunk][:]
+//   D  seg_sum       four waves per (code, chunk): fp32 sums of their 128 rows in position order, added in wave order -> partial[chunk][:]
 //   E  seg_final     per code: partials in chunk order                                      -> out[k][:]
 #include "nsg_common.h"
 
 namespace {
 
 constexpr int SEG_ROWS = 1024;      // rows per block of the counting sort
-constexpr int SEG_CH = 128;         // rows per summation chunk
+constexpr int SEG_CH = 512;         // rows per summation chunk: 4 waves x 128 rows
 
 struct SegLayout {
     size_t blockcnt, total, base, chunkbase, perm, partial, bytes;
@@ -57,26 +57,47 @@ __global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t *__restrict
     for (int k = threadIdx.x; k < K; k += 256) blockcnt[(size_t)blockIdx.x * K + k] = bins[k];
 }
 
+// blockcnt[b][k] -> its exclusive scan over b (in place), total[k], counts[k].  Block = 32 codes x 8 segments of the block range:
+// a thread loads its whole segment at once (SEG_SCAN_MAX values in registers: two memory round trips per thread in all instead
+// of one per 8 blocks), the 8 segment totals of a code meet in LDS.
+constexpr int SEG_SCAN_MAX = 96;     // blocks per segment held in registers: nb <= 8 * 96 per pass (more: further passes carry the sum)
 __global__ __launch_bounds__(256) void seg_scan_blk_kernel(int *__restrict__ blockcnt, int nb, int K, int *__restrict__ total, float *__restrict__ counts)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    int run = 0;
-    int b = 0;
-    for (; b + 8 <= nb; b += 8) {           // loads eight at a time (they are independent), the running sum in block order
-        int c[8];
+    __shared__ int segsum[8][32];
+    const int kk = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kk;
+    const bool live = k < K;
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 8 * SEG_SCAN_MAX) {
+        const int span = min(nb - b0, 8 * SEG_SCAN_MAX);
+        const int per = (span + 7) / 8;                    // blocks per segment in this pass (<= SEG_SCAN_MAX)
+        const int s0 = b0 + seg * per, s1 = min(b0 + span, s0 + per);
+        int c[SEG_SCAN_MAX];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = blockcnt[(size_t)(b + j) * K + k];
+        for (int j = 0; j < SEG_SCAN_MAX; ++j) {          // unconditional (clamped) loads, then the select: no branch per load
+            const int v = blockcnt[(size_t)min(s0 + j, nb - 1) * K + (live ? k : 0)];
+            c[j] = (live && s0 + j < s1) ? v : 0;
+        }
+        int sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { blockcnt[(size_t)(b + j) * K + k] = run; run += c[j]; }
+        for (int j = 0; j < SEG_SCAN_MAX; ++j) sum += c[j];
+        segsum[seg][kk] = sum;
+        __syncthreads();
+        int run = carry, all = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int v = segsum[q][kk]; run += q < seg ? v : 0; all += v; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SEG_SCAN_MAX; ++j) {
+            if (live && s0 + j < s1) blockcnt[(size_t)(s0 + j) * K + k] = run;
+            run += c[j];
+        }
+        carry += all;
     }
-    for (; b < nb; ++b) {
-        const int c = blockcnt[(size_t)b * K + k];
-        blockcnt[(size_t)b * K + k] = run;
-        run += c;
+    if (live && seg == 0) {
+        total[k] = carry;
+        if (counts) counts[k] = (float)carry;
     }
-    total[k] = run;
-    if (counts) counts[k] = (float)run;
 }
 
 // one block of 1024 threads: exclusive scans over the codes of total[] (-> base) and of ceil(total / SEG_CH) (-> chunkbase)
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(64) void seg_place_kernel(const int64_t *__restrict
 
 // one wave per chunk: rows perm[p0 .. p1) of code k summed in position order.  D = 4 * 64 * RPL... a lane owns one 16-byte piece
 // of a row; a wave-wide load covers 1024 / (4 D) rows; lanes that own the same piece of different rows are combined in lane order.
-__global__ __launch_bounds__(64) void seg_sum_kernel(const float *__restrict__ g, const int *__restrict__ perm, const int *__restrict__ total,
+__global__ __launch_bounds__(256) void seg_sum_kernel(const float *__restrict__ g, const int *__restrict__ perm, const int *__restrict__ total,
                                                      const int *__restrict__ base, const int *__restrict__ chunkbase, int K, int D,
                                                      float *__restrict__ partial)
 {
@@ -166,8 +187,9 @@ __global__ __launch_bounds__(64) void seg_sum_kernel(const float *__restrict__ g
     }
     const int k = lo;
     const int j = chunk - chunkbase[k];
-    const int p0 = base[k] + j * SEG_CH, p1 = min(base[k] + total[k], p0 + SEG_CH);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pend = min(base[k] + total[k], base[k] + (j + 1) * SEG_CH);
+    const int p0 = min(pend, base[k] + j * SEG_CH + wave * (SEG_CH / 4)), p1 = min(pend, p0 + SEG_CH / 4);   // this wave's quarter
     const int ppr = D >> 2;                 // 16-byte pieces per row (D % 4 == 0)
     const int rpi = 64 / ppr;               // rows per wave-wide load when ppr <= 64
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -190,35 +212,61 @@ __global__ __launch_bounds__(64) void seg_sum_kernel(const float *__restrict__ g
         for (; p < p1; p += rpi) {
             if (act && p + sub < p1) acc += *reinterpret_cast<const v4f *>(g + (size_t)perm[p + sub] * D + pc * 4);
         }
-        // combine the rpi sub-rows of each piece in sub order through LDS
-        __shared__ v4f red[64];
-        red[lane] = acc;
+        // combine the rpi sub-rows of each piece in sub order, then the four waves in wave order, through LDS
+        __shared__ v4f red[256];
+        red[threadIdx.x] = acc;
         __syncthreads();
-        if (lane < ppr) {
-            v4f s = red[lane];
-            for (int q = 1; q < rpi; ++q) s += red[q * ppr + lane];
-            *reinterpret_cast<v4f *>(partial + (size_t)chunk * D + lane * 4) = s;
+        if (threadIdx.x < ppr) {
+            v4f s = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < 4; ++w) {
+                v4f sw = red[64 * w + threadIdx.x];
+                for (int q = 1; q < rpi; ++q) sw += red[64 * w + q * ppr + threadIdx.x];
+                s += sw;
+            }
+            *reinterpret_cast<v4f *>(partial + (size_t)chunk * D + threadIdx.x * 4) = s;
         }
     } else {
-        for (int pc = lane; pc < ppr; pc += 64) {        // wide rows: a lane walks its pieces
+        for (int pc = threadIdx.x; pc < ppr; pc += 256) {        // wide rows: a thread walks its pieces over the whole chunk
             v4f s = {0.f, 0.f, 0.f, 0.f};
-            for (int p = p0; p < p1; ++p) s += *reinterpret_cast<const v4f *>(g + (size_t)perm[p] * D + pc * 4);
+            for (int p = base[k] + j * SEG_CH; p < pend; ++p) s += *reinterpret_cast<const v4f *>(g + (size_t)perm[p] * D + pc * 4);
             *reinterpret_cast<v4f *>(partial + (size_t)chunk * D + pc * 4) = s;
         }
     }
 }
 
+// one block per code: 256 threads = (pieces of a row) x G groups; group q adds the chunks q, q + G, ... of the code in that order,
+// eight loads in flight, and the G group sums are added in group order -- a fixed shape whatever the code's share of the rows (a
+// collapsed codebook puts most rows, hence thousands of partials, on a few codes)
 __global__ __launch_bounds__(256) void seg_final_kernel(const float *__restrict__ partial, const int *__restrict__ chunkbase, int K, int D,
                                                         float *__restrict__ out)
 {
+    __shared__ v4f red[256];
+    const int k = blockIdx.x;
     const int ppr = D >> 2;
-    const int64_t totalp = (int64_t)K * ppr;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < totalp; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i / ppr), pc = (int)(i - (int64_t)k * ppr);
-        const int c0 = chunkbase[k], c1 = chunkbase[k + 1];
+    const int c0 = chunkbase[k], c1 = chunkbase[k + 1];
+    for (int pb = 0; pb < ppr; pb += 256) {                 // (D > 1024: several passes)
+        const int P = min(ppr - pb, 256);                   // pieces in this pass: a power of two <= 64, or a multiple of 64
+        const int G = P <= 64 ? 256 / P : 1;
+        const int pc = pb + (int)threadIdx.x % P, q = (int)threadIdx.x / P;
+        const bool act = (int)threadIdx.x < P * G;
         v4f s = {0.f, 0.f, 0.f, 0.f};
-        for (int c = c0; c < c1; ++c) s += *reinterpret_cast<const v4f *>(partial + (size_t)c * D + pc * 4);
-        *reinterpret_cast<v4f *>(out + (size_t)k * D + pc * 4) = s;
+        int c = c0 + q;
+        for (; c + 7 * G < c1; c += 8 * G) {
+            v4f v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const v4f *>(partial + (size_t)(c + u * G) * D + (act ? pc : 0) * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < c1; c += G) s += *reinterpret_cast<const v4f *>(partial + (size_t)c * D + (act ? pc : 0) * 4);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if ((int)threadIdx.x < P) {
+            v4f t = red[threadIdx.x];
+            for (int g2 = 1; g2 < G; ++g2) t += red[g2 * P + threadIdx.x];
+            *reinterpret_cast<v4f *>(out + (size_t)k * D + pc * 4) = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -248,7 +296,7 @@ int nsg_index_add_rows_sorted(const int64_t *idx, const float *g, int64_t N, int
     float *partial = reinterpret_cast<float *>(ws + L.partial);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(seg_hist_kernel, dim3(L.nb), dim3(256), (size_t)K * 4, s, idx, N, K, blockcnt);
-    hipLaunchKernelGGL(seg_scan_blk_kernel, dim3((K + 255) / 256), dim3(256), 0, s, blockcnt, L.nb, K, total, counts_out);
+    hipLaunchKernelGGL(seg_scan_blk_kernel, dim3((K + 31) / 32), dim3(256), 0, s, blockcnt, L.nb, K, total, counts_out);
     hipLaunchKernelGGL(seg_scan_code_kernel, dim3(1), dim3(1024), 0, s, total, K, base, chunkbase);
     static LdsOptIn once;
     if ((size_t)K * 12 > 65536 - 1024) {
@@ -256,9 +304,8 @@ int nsg_index_add_rows_sorted(const int64_t *idx, const float *g, int64_t N, int
         if (rc != NSG_OK) return rc;
     }
     hipLaunchKernelGGL(seg_place_kernel, dim3(L.nb), dim3(64), (size_t)K * 12, s, idx, N, K, blockcnt, base, perm);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)L.maxchunks), dim3(64), 0, s, g, perm, total, base, chunkbase, K, D, partial);
-    const int64_t nb = nsg_cdiv((int64_t)K * (D / 4), 256);
-    hipLaunchKernelGGL(seg_final_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, s, partial, chunkbase, K, D, out);
+    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)L.maxchunks), dim3(256), 0, s, g, perm, total, base, chunkbase, K, D, partial);
+    hipLaunchKernelGGL(seg_final_kernel, dim3((unsigned)K), dim3(256), 0, s, partial, chunkbase, K, D, out);
     return nsg_check_launch("index_add_rows_sorted");
 }
 
