@@ -349,6 +349,17 @@ NSG_API int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const f
                                           float *dh_colsum, const void *prev_x, const float *prev_mean, const float *prev_invstd,
                                           const float *prev_gamma, const float *prev_beta, float *prev_dgamma, float *prev_dbeta,
                                           int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes, void *stream);
+/* nsg_bn_backward_conv1x1_dgrad + nsg_bn_relu_conv1x1_wgrad in ONE pass over the tensors (bf16, C = 128; the BatchNorm in front is
+ * required): dx, dh_colsum (or NULL), prev_dgamma / prev_dbeta as above, and dw[o][i] = sum_m dh[m][o] * relu(bn_prev(prev_x))[m][i]
+ * (the autograd of src/models.py:153 for the conv weight).  dh is never stored.  4 tensor passes instead of 7. */
+NSG_API int32_t nsg_bn_backward_conv1x1_dgrad_wgrad_supported(int32_t dtype, int32_t C);
+NSG_API size_t nsg_bn_backward_conv1x1_dgrad_wgrad_workspace_bytes(int64_t M, int32_t C);
+NSG_API int nsg_bn_backward_conv1x1_dgrad_wgrad(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma,
+                                                const float *dgamma, const float *dbeta, const float *w, void *dx, float *dw,
+                                                float *dh_colsum, const void *prev_x, const float *prev_mean, const float *prev_invstd,
+                                                const float *prev_gamma, const float *prev_beta, float *prev_dgamma, float *prev_dbeta,
+                                                int64_t M, int32_t C, int32_t dtype, void *workspace, size_t workspace_bytes,
+                                                void *stream);
 /* The apply half of nsg_bn_backward alone: dgamma / dbeta are inputs. */
 NSG_API int nsg_bn_backward_apply(const void *x, const void *y_relu, const void *dy, const float *mean, const float *invstd,
                                   const float *gamma, const float *relu_beta, const float *dgamma, const float *dbeta, void *dx,

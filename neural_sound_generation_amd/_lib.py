@@ -84,6 +84,9 @@ _SIGS = {
     "nsg_bn_relu_conv1x1_wgrad": (None, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_bn_backward_conv1x1_dgrad": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P,
                                              c_size_t, _P]),
+    "nsg_bn_backward_conv1x1_dgrad_wgrad_supported": (c_int32, [c_int32, c_int32]),
+    "nsg_bn_backward_conv1x1_dgrad_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "nsg_bn_backward_conv1x1_dgrad_wgrad": (None, [_P] * 18 + [c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_bn_backward_apply": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_bn_backward_sums": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_relu_backward_add": (None, [_P, _P, _P, _P, c_int64, c_int32, _P]),

@@ -21,6 +21,12 @@ int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean
                                 const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks,
                                 const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
                                 const float *prev_beta, float **prev_partial, hipStream_t s);
+bool nsg_flat1x1_fused_bwd_supported(int dtype, int C);
+size_t nsg_flat1x1_fused_bwd_workspace_bytes(int C);
+int nsg_launch_flat1x1_fused_bwd(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
+                                 const float *dbeta, const float *w, void *dx, float *dw, int64_t M, int C, void *ws, int *nblocks,
+                                 const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
+                                 const float *prev_beta, float **colsum_partial, float **prev_partial, hipStream_t s);
 // c1_mfma.hip / stencil_c1.hip: pieces of the fused output layer (nsg_bn_relu_c1convt_*)
 bool nsg_c1m_supported(int C);
 int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
@@ -769,6 +775,41 @@ int nsg_bn_backward_conv1x1_dgrad(const void *h, const void *dy, const float *me
     }
     if (prev_x) return nsg_launch_bn_bwd_final(prev_partial, nblocks, C, prev_dgamma, prev_dbeta, s);
     return NSG_OK;
+}
+
+int32_t nsg_bn_backward_conv1x1_dgrad_wgrad_supported(int32_t dtype, int32_t C) { return nsg_flat1x1_fused_bwd_supported(dtype, C) ? 1 : 0; }
+
+size_t nsg_bn_backward_conv1x1_dgrad_wgrad_workspace_bytes(int64_t M, int32_t C)
+{
+    if (M <= 0 || !nsg_flat1x1_fused_bwd_supported(NSG_BF16, C)) return 0;
+    return nsg_flat1x1_fused_bwd_workspace_bytes(C);
+}
+
+int nsg_bn_backward_conv1x1_dgrad_wgrad(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma,
+                                        const float *dgamma, const float *dbeta, const float *w, void *dx, float *dw, float *dh_colsum,
+                                        const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
+                                        const float *prev_beta, float *prev_dgamma, float *prev_dbeta, int64_t M, int32_t C, int32_t dtype,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *fn = "nsg_bn_backward_conv1x1_dgrad_wgrad";
+    NSG_REQUIRE(h && dy && mean && invstd && gamma && dgamma && dbeta && w && dx && dw && prev_x && prev_mean && prev_invstd && prev_gamma &&
+                prev_beta && prev_dgamma && prev_dbeta, NSG_E_INVALID, "nsg_bn_backward_conv1x1_dgrad_wgrad: null pointer");
+    if (!nsg_flat1x1_fused_bwd_supported(dtype, C)) return nsg_fail(NSG_E_UNSUPPORTED, "%s: needs bf16 tensors and C = 128 (use nsg_bn_backward_conv1x1_dgrad + nsg_bn_relu_conv1x1_wgrad otherwise)", fn);
+    if (M <= 0 || M >= 0x7fffffffLL / C) return nsg_fail(NSG_E_UNSUPPORTED, "%s: M = %lld rows not supported", fn, (long long)M);
+    if (!workspace || workspace_bytes < nsg_flat1x1_fused_bwd_workspace_bytes(C)) return nsg_fail(NSG_E_WORKSPACE, "%s: workspace too small", fn);
+    NSG_REQUIRE(nsg_aligned16(h) && nsg_aligned16(dy) && nsg_aligned16(dx) && nsg_aligned16(prev_x), NSG_E_INVALID,
+                "nsg_bn_backward_conv1x1_dgrad_wgrad: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int nblocks = 0;
+    float *colsum_partial = nullptr, *prev_partial = nullptr;
+    int rc = nsg_launch_flat1x1_fused_bwd(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dx, dw, M, C, workspace, &nblocks, prev_x, prev_mean,
+                                          prev_invstd, prev_gamma, prev_beta, &colsum_partial, &prev_partial, s);
+    if (rc) return rc;
+    if (dh_colsum) {
+        rc = nsg_launch_slab_sum_final(colsum_partial, nblocks, C, dh_colsum, s);
+        if (rc) return rc;
+    }
+    return nsg_launch_bn_bwd_final(prev_partial, nblocks, C, prev_dgamma, prev_dbeta, s);
 }
 
 }  // extern "C"

@@ -628,6 +628,229 @@ int launch_flat_wide(const FlatParams &p, int blocks, hipStream_t s)
     return nsg_check_launch("flat_wide_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// C = 128: the backward of the 1x1 conv in ONE pass -- flat_gemm_kernel<4, 1> (dh = BatchNorm backward of dy, dx = dh * W, the
+// sums of the BatchNorm + ReLU in front) AND the conv's weight gradient dw[co][ci] = sum_rows dh[row][co] * a[row][ci] with
+// a = relu(bn_front(prev_x)) rebuilt from the prev_x rows the kernel loads anyway.  dh is never stored (the weight gradient was
+// its only reader) and prev_x / dh are not read a second time by a weight-gradient kernel: 4 tensor passes instead of 7.
+// 512 threads, one block per CU.  Wave w: data gradient rows 32 (w & 3) .. +31 x input channels 64 (w >> 2) .. +63;
+// weight gradient output channels 32 (w & 3) .. +31 x input channels 64 (w >> 2) .. +63, accumulated over all the block's tiles
+// (two MFMA tiles in registers), operands read TRANSPOSED from the row-major LDS tiles (ds_read_b64_tr_b16, as wgrad_gemm_bf16).
+// Per block a [128][128] fp32 partial of dw; nsg_launch_wgrad_reduce adds them in block order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ s16x4 flat_tr_read(const bf16_t *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+}
+
+__global__ __launch_bounds__(512) void flat_bwd_fused_kernel(const FlatParams p, float *__restrict__ dw_partial)
+{
+    constexpr int C = 128, NT = 512, KS = C / 16, PITCH = C + 8, CPR = C / 8, RSTEP = NT / CPR, PIECES = ROWS / RSTEP;   // 32 rows per step, 4 pieces
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t *wt = reinterpret_cast<bf16_t *>(smem_raw);            // [C (n = ci)][PITCH (k = co)]
+    bf16_t *tdh = wt + C * PITCH;                                 // [ROWS][PITCH] dh
+    bf16_t *ta = tdh + ROWS * PITCH;                              // [ROWS][PITCH] a = relu(bn_front(prev_x))
+    bf16_t *tout = ta + ROWS * PITCH;                             // [ROWS][PITCH] dx on its way out
+    __shared__ __attribute__((aligned(16))) float sconst[8 * C];  // sc, k1, k2 | front: mean, fs, beta | front: fs, off (the forward's form)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hb = lane >> 5;
+    const int wr = wave & 3, wc = wave >> 2;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+    {   // W^T -> LDS as bf16 [n = ci][k = co]: lanes along n (rows k, k + 1 of w), all loads first
+        constexpr int WIT = C * C / 2 / NT;
+        float wa[WIT], wb[WIT];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + NT * it, n = i % C, k = (i / C) * 2;
+            wa[it] = p.w[(size_t)k * C + n];
+            wb[it] = p.w[(size_t)(k + 1) * C + n];
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + NT * it, n = i % C, k = (i / C) * 2;
+            *reinterpret_cast<unsigned *>(wt + n * PITCH + k) = pack_bf16(wa[it], wb[it]);
+        }
+    }
+    if (tid < C) {
+        const int c = tid;
+        const float sc = p.gamma[c] * p.invstd[c];
+        const float k1 = sc * p.invstd[c] * (p.dgamma[c] * p.inv_m);
+        sconst[c] = sc;
+        sconst[C + c] = k1;
+        sconst[2 * C + c] = __builtin_fmaf(sc, p.dbeta[c] * p.inv_m, -(k1 * p.mean[c]));
+        const float fs = p.prev_invstd[c] * p.prev_gamma[c];
+        sconst[3 * C + c] = p.prev_mean[c];
+        sconst[4 * C + c] = fs;
+        sconst[5 * C + c] = p.prev_beta[c];
+        sconst[6 * C + c] = fs;
+        sconst[7 * C + c] = __builtin_fmaf(-p.prev_mean[c], fs, p.prev_beta[c]);     // the forward's staging constants (flat_gemm_kernel MODE 0)
+    }
+    __syncthreads();
+    const int prow = tid / CPR, cc8 = (tid % CPR) * 8;
+    auto consts = [&](int j, float (&v)[8]) __attribute__((always_inline)) {
+        const v4f a = *reinterpret_cast<const v4f *>(sconst + j * C + cc8), b = *reinterpret_cast<const v4f *>(sconst + j * C + cc8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    };
+    float csum[8], ps1[8], ps2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { csum[e] = 0.f; ps1[e] = 0.f; ps2[e] = 0.f; }
+    const int64_t ntiles = (p.M + ROWS - 1) / ROWS;
+    const int64_t G = gridDim.x;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(unsigned)((size_t)p.M * C * sizeof(bf16_t)), 0x00020000);
+
+    // register sets: (h, dy, prev_x) of the tile being staged; prev_x of the tile in LDS is kept for its store phase
+    v4f px[PIECES], pg[PIECES], ph[PIECES], phc[PIECES];
+    auto prefetch = [&](int64_t t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int64_t m = t * ROWS + prow + RSTEP * i;
+            const size_t off = (size_t)(m < p.M ? m : p.M - 1) * C + cc8;     // clamped: always inside the tensors
+            px[i] = *reinterpret_cast<const v4f *>(p.x + off);
+            pg[i] = *reinterpret_cast<const v4f *>(p.g + off);
+            ph[i] = *reinterpret_cast<const v4f *>(p.prev_x + off);
+        }
+    };
+    auto stage = [&](int64_t t) __attribute__((always_inline)) {       // registers -> dh and a -> LDS; rows past the end are ZERO in both (they enter dw)
+        float k0[8], k1[8], k2[8], fs[8], fo[8];
+        consts(0, k0); consts(1, k1); consts(2, k2); consts(6, fs); consts(7, fo);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = prow + RSTEP * i;
+            const bool in = t * ROWS + row < p.M;
+            float xv[8], gv[8], hv[8], o[8], a[8];
+            Elem<bf16_t>::unpack16(px[i], xv);
+            Elem<bf16_t>::unpack16(pg[i], gv);
+            Elem<bf16_t>::unpack16(ph[i], hv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = in ? __builtin_fmaf(k0[e], gv[e], -__builtin_fmaf(k1[e], xv[e], k2[e])) : 0.f;
+                a[e] = in ? fmaxf(__builtin_fmaf(hv[e], fs[e], fo[e]), 0.f) : 0.f;
+                csum[e] += o[e];
+            }
+            const v4u pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7])};
+            const v4u pa = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(a[4], a[5]), pack_bf16(a[6], a[7])};
+            *reinterpret_cast<v4u *>(tdh + row * PITCH + cc8) = pk;
+            *reinterpret_cast<v4u *>(ta + row * PITCH + cc8) = pa;
+            phc[i] = ph[i];
+        }
+    };
+    v16f dw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[j][r] = 0.f;
+
+    prefetch(blockIdx.x);
+    stage(blockIdx.x);
+    __syncthreads();
+    // transposing reads: lane = 32 h + 16 g16 + 4 q + pp supplies row 8 h + q (+ 4), columns 16 g16 + 4 pp .. + 3 of a 32-channel block
+    const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    const bf16_t *trA = tdh + (8 * hb + q) * PITCH + 32 * wr + 16 * g16 + 4 * pp;
+    const bf16_t *trB = ta + (8 * hb + q) * PITCH + 64 * wc + 16 * g16 + 4 * pp;
+    for (int64_t t = blockIdx.x; t < ntiles; t += G) {
+        const int64_t nxt = t + G;
+        prefetch(nxt);                         // (past the end: clamped loads, staged as zeros)
+        // ---- data gradient: out^T[n = ci][row] = W^T[ci][co] * dh^T[co][row] ----
+        v16f acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const bf16_t *brow = tdh + (32 * wr + l31) * PITCH + 8 * hb;
+        const bf16_t *arow = wt + (64 * wc + l31) * PITCH + 8 * hb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f *>(brow + 16 * ks));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const v4f *>(arow + 32 * j * PITCH + 16 * ks));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        // ---- weight gradient: dw[co][ci] += sum over the tile's rows of dh[row][co] * a[row][ci] ----
+#pragma unroll
+        for (int ks = 0; ks < ROWS / 16; ++ks) {
+            const s16x4 alo = flat_tr_read(trA + (16 * ks) * PITCH), ahi = flat_tr_read(trA + (16 * ks + 4) * PITCH);
+            const s16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const s16x4 blo = flat_tr_read(trB + (16 * ks) * PITCH + 32 * j), bhi = flat_tr_read(trB + (16 * ks + 4) * PITCH + 32 * j);
+                const s16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                dw[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), dw[j], 0, 0, 0);
+            }
+        }
+        // dx block -> LDS: lane = row 32 wr + l31; registers 4 qq .. 4 qq + 3 of block j = channels 64 wc + 32 j + 8 qq + 4 hb .. + 3
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int ch = 64 * wc + 32 * j + 8 * qq + 4 * hb;
+                const v2u pk = {pack_bf16(acc[j][4 * qq], acc[j][4 * qq + 1]), pack_bf16(acc[j][4 * qq + 2], acc[j][4 * qq + 3])};
+                *reinterpret_cast<v2u *>(tout + (32 * wr + l31) * PITCH + ch) = pk;
+            }
+        __syncthreads();                       // dx is complete; every wave is done with dh and a
+        float pmu[8], pfs[8], pbe[8];
+        consts(3, pmu); consts(4, pfs); consts(5, pbe);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = prow + RSTEP * i;
+            const int64_t m = t * ROWS + row;
+            const bool in = m < p.M;
+            const v4f piece = *reinterpret_cast<const v4f *>(tout + row * PITCH + cc8);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, piece), rs_out, (int)(in ? (unsigned)(((size_t)m * C + cc8) * 2) : OOB), 0, 0);
+            float dv[8], hv[8];                // bn_bwd_partial_kernel's sums on (prev_x, the dx values as stored), same mask expression
+            Elem<bf16_t>::unpack16(piece, dv);
+            Elem<bf16_t>::unpack16(phc[i], hv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float hc = hv[e] - pmu[e];
+                const float ge = (in && (hc * pfs[e] + pbe[e]) > 0.f) ? dv[e] : 0.f;
+                ps1[e] += ge;
+                ps2[e] = __builtin_fmaf(ge, hc, ps2[e]);
+            }
+        }
+        stage(nxt);
+        __syncthreads();
+    }
+    // ---- this block's share of dw: [co][ci] fp32; lane = ci column, registers = co rows (r & 3) + 8 (r >> 2) + 4 hb ----
+    {
+        float *dst = dw_partial + (size_t)blockIdx.x * C * C;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * wr + (r & 3) + 8 * (r >> 2) + 4 * hb;
+                dst[(size_t)co * C + 64 * wc + 32 * j + l31] = dw[j][r];
+            }
+    }
+    // ---- closing reductions over the threads of a channel group, in row-slot order ----
+    float *red = reinterpret_cast<float *>(smem_raw);      // [16][NT] floats (the loop ended on a barrier)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[e * NT + tid] = ps1[e]; red[(8 + e) * NT + tid] = ps2[e]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
+        const int grp = c >> 3, e = c & 7;
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < RSTEP; ++r) { a += red[e * NT + r * CPR + grp]; b += red[(8 + e) * NT + r * CPR + grp]; }
+        p.prev_partial[(size_t)blockIdx.x * 2 * C + c] = a;
+        p.prev_partial[(size_t)blockIdx.x * 2 * C + C + c] = b * p.prev_invstd[c];
+    }
+    __syncthreads();
+    if (p.colsum_partial) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[e * NT + tid] = csum[e];
+        __syncthreads();
+        for (int c = tid; c < C; c += NT) {
+            const int grp = c >> 3, e = c & 7;
+            float sacc = 0.f;
+            for (int r = 0; r < RSTEP; ++r) sacc += red[e * NT + r * CPR + grp];
+            p.colsum_partial[(size_t)blockIdx.x * C + c] = sacc;
+        }
+    }
+}
+
 template <int NB, int MODE>
 int launch_flat(const FlatParams &p, int blocks, hipStream_t s)
 {
@@ -689,6 +912,46 @@ int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *in
     if (nblocks) *nblocks = blocks;
     if (C == 256 && !nsg_aligned16(w)) return nsg_fail(NSG_E_INVALID, "flat_gemm (C = 256): w must be 16-byte aligned");
     return dispatch_flat<0>(p, C, blocks, s);
+}
+
+// The backward of the 1x1 conv in one pass (C = 128): dx, the column sums of dh, the sums of the BatchNorm in front, and dw
+// (partials per block in the workspace, reduced here).  dh itself is not stored.
+constexpr int FLAT_FUSED_BLOCKS = 256;
+bool nsg_flat1x1_fused_bwd_supported(int dtype, int C) { return dtype == NSG_BF16 && C == 128; }
+size_t nsg_flat1x1_fused_bwd_workspace_bytes(int C)
+{
+    return nsg_align_up((size_t)FLAT_FUSED_BLOCKS * C * sizeof(float), 256) + nsg_align_up((size_t)FLAT_FUSED_BLOCKS * 2 * C * sizeof(float), 256) +
+           (size_t)FLAT_FUSED_BLOCKS * C * C * sizeof(float);
+}
+int nsg_launch_flat1x1_fused_bwd(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
+                                 const float *dbeta, const float *w, void *dx, float *dw, int64_t M, int C, void *ws, int *nblocks,
+                                 const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
+                                 const float *prev_beta, float **colsum_partial, float **prev_partial, hipStream_t s)
+{
+    char *wsb = reinterpret_cast<char *>(ws);
+    FlatParams p = {};
+    p.x = reinterpret_cast<const bf16_t *>(h); p.g = reinterpret_cast<const bf16_t *>(dy); p.w = w;
+    p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.dgamma = dgamma; p.dbeta = dbeta; p.inv_m = 1.f / (float)M;
+    p.prev_x = reinterpret_cast<const bf16_t *>(prev_x);
+    p.prev_mean = prev_mean; p.prev_invstd = prev_invstd; p.prev_gamma = prev_gamma; p.prev_beta = prev_beta;
+    p.colsum_partial = reinterpret_cast<float *>(wsb);
+    p.prev_partial = reinterpret_cast<float *>(wsb + nsg_align_up((size_t)FLAT_FUSED_BLOCKS * C * sizeof(float), 256));
+    float *dwp = reinterpret_cast<float *>(wsb + nsg_align_up((size_t)FLAT_FUSED_BLOCKS * C * sizeof(float), 256) +
+                                           nsg_align_up((size_t)FLAT_FUSED_BLOCKS * 2 * C * sizeof(float), 256));
+    p.out = reinterpret_cast<bf16_t *>(dx); p.M = M;
+    const int64_t nt = (M + ROWS - 1) / ROWS;
+    const int blocks = (int)(nt < FLAT_FUSED_BLOCKS ? nt : FLAT_FUSED_BLOCKS);
+    *nblocks = blocks;
+    *colsum_partial = p.colsum_partial;
+    *prev_partial = p.prev_partial;
+    const size_t lds = (size_t)(C + 3 * ROWS) * (C + 8) * sizeof(bf16_t);
+    static LdsOptIn once;
+    int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&flat_bwd_fused_kernel)}, lds, "flat_gemm (fused backward)");
+    if (rc != NSG_OK) return rc;
+    hipLaunchKernelGGL(flat_bwd_fused_kernel, dim3(blocks), dim3(512), lds, s, p, dwp);
+    rc = nsg_check_launch("flat_bwd_fused_kernel");
+    if (rc != NSG_OK) return rc;
+    return nsg_launch_wgrad_reduce(dwp, dw, blocks, 1, C, C, s);
 }
 
 // dh = BatchNorm backward of dy at input h (no ReLU), stored; dx = dh * W; partial column sums of dh -> colsum_partial [blocks][C];

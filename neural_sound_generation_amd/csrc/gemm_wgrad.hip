@@ -804,6 +804,18 @@ int nsg_wgrad_strip_slabs(int ntaps, int A, int C);
 bool nsg_wgrad_strip_applicable(const WgradParams &p);
 int nsg_launch_wgrad_strip(const WgradParams &p, int *nslab, hipStream_t s);
 
+// dst[(a*C + c)*ntaps + t] = sum over slabs (slab order) of partial[slab][t][a][c]: the closing pass of every weight gradient,
+// also used by gemm_flat.hip's fused data + weight gradient of the 1x1 conv
+int nsg_launch_wgrad_reduce(const float *partial, float *dst, int nslab, int ntaps, int A, int C, hipStream_t s)
+{
+    const int64_t total = (int64_t)ntaps * A * C;
+    const int split = (nslab >= 64 && total < 512 * 256) ? 8 : 1;   // few outputs, many slabs: share the slabs
+    const int64_t nb = nsg_cdiv(total, 256 / split);
+    const int blocks = (int)(nb > 4096 ? 4096 : nb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dst, nslab, ntaps, A, C, split);
+    return nsg_check_launch("wgrad_reduce_kernel");
+}
+
 size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C)
 {
     const SlabPlan sp = plan_slabs(Mp, ntaps, A, C);

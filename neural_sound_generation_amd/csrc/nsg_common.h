@@ -230,6 +230,7 @@ int nsg_patch_gemm_stat_records(const GatherGemmParams &p);     // statistics re
 size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C);
 // dst[(a*C + c)*ntaps + t] = sum over slabs (fixed order) of partial; dst fully overwritten.
 int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipStream_t s);
+int nsg_launch_wgrad_reduce(const float *partial, float *dst, int nslab, int ntaps, int A, int C, hipStream_t s);
 
 // tile-statistics records [ntiles][3][C] (count, sum, M2 about the tile mean) -> mean / invstd / running statistics.
 // The buffer must be nsg_bn_tiles_bytes(ntiles, C) long (the finalizer keeps its chunk records behind the tiles).

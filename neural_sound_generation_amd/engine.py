@@ -117,6 +117,7 @@ def _bump(bn: "BNParams"):
 # of 183-185 (the sums ride in the store phase, plus two finalizer launches) and the transposed conv 450 us instead of 389:
 # 9.525 vs 9.60-9.63 ms per step (-0.8 %) while the conv kernel's own roofline fraction drops 5 %.  Off by default
 # (NSG_PATCH_BN_STATS=1 turns it on).
+FUSED_1X1_BWD = _os.environ.get("NSG_FUSED_1X1_BWD", "1") == "1"    # the 1x1 conv's data and weight gradients in one kernel (C = 128)
 PATCH_BN_STATS = _os.environ.get("NSG_PATCH_BN_STATS", "0") == "1"
 
 
@@ -194,9 +195,14 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     dbias1 = o[1] if o[1] is not None else torch.empty(D, dtype=torch.float32, device=h2.device)
     if a1 is None:      # flat-GEMM 1x1: bn2's sums, then its apply + the conv's data gradient in one pass, the weight gradient from h1
         dg2, db2n = ops.bn_backward_sums(h2, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7])
-        dh2, da1, dg1, db1n = ops.bn_backward_conv1x1_dgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight, dh_colsum=dbias2,
-                                                            prev=(h1, m1, i1, P.bn1.weight, P.bn1.bias), prev_dgamma=o[2], prev_dbeta=o[3])
-        dw2 = ops.bn_relu_conv1x1_wgrad(h1, m1, i1, P.bn1.weight, P.bn1.bias, dh2, dw=o[4])
+        if FUSED_1X1_BWD and ops.bn_backward_conv1x1_dgrad_wgrad_supported(h2.dtype, D):     # data + weight gradient in one pass, dh2 never stored
+            da1, dw2, dg1, db1n = ops.bn_backward_conv1x1_dgrad_wgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight,
+                                                                      (h1, m1, i1, P.bn1.weight, P.bn1.bias), dh_colsum=dbias2, dw=o[4],
+                                                                      prev_dgamma=o[2], prev_dbeta=o[3])
+        else:
+            dh2, da1, dg1, db1n = ops.bn_backward_conv1x1_dgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight, dh_colsum=dbias2,
+                                                                prev=(h1, m1, i1, P.bn1.weight, P.bn1.bias), prev_dgamma=o[2], prev_dbeta=o[3])
+            dw2 = ops.bn_relu_conv1x1_wgrad(h1, m1, i1, P.bn1.weight, P.bn1.bias, dh2, dw=o[4])
         dh1 = ops.bn_backward_apply(h1, da1, m1, i1, P.bn1.weight, dg1, db1n, relu_beta=P.bn1.bias, dx_colsum=dbias1)   # bn1's sums came with da1
     else:
         dh2, dg2, db2n = ops.bn_backward(h2, None, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7], dx_colsum=dbias2)

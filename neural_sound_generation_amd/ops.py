@@ -612,6 +612,33 @@ def bn_backward_conv1x1_dgrad(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dh_c
     return dh, dx
 
 
+def bn_backward_conv1x1_dgrad_wgrad_supported(dtype, C) -> bool:
+    return bool(_lib.query("nsg_bn_backward_conv1x1_dgrad_wgrad_supported", c_int32(nsg_dtype(dtype)), c_int32(C)))
+
+
+def bn_backward_conv1x1_dgrad_wgrad(h, dy, mean, invstd, gamma, dgamma, dbeta, w, prev, dh_colsum=None, dw=None, prev_dgamma=None,
+                                    prev_dbeta=None):
+    """bn_backward_conv1x1_dgrad(..., prev=...) and bn_relu_conv1x1_wgrad in one pass over the tensors: returns
+    (dx, dw, prev_dgamma, prev_dbeta); dh is not stored (include/nsg.h: nsg_bn_backward_conv1x1_dgrad_wgrad)."""
+    _chk(h, "h", None); _chk(dy, "dy", h.dtype); _chk(w, "w", torch.float32)
+    C = h.shape[-1]
+    M = h.numel() // C
+    px, pm, pi, pg, pb = prev
+    _chk(px, "prev_x", h.dtype)
+    dev = h.device
+    dx = torch.empty_like(h)
+    dw = dw if dw is not None else torch.empty_like(w)
+    prev_dgamma = prev_dgamma if prev_dgamma is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    prev_dbeta = prev_dbeta if prev_dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    nb = _lib.query("nsg_bn_backward_conv1x1_dgrad_wgrad_workspace_bytes", c_int64(M), c_int32(C))
+    ws = WS.get(nb, dev)
+    _lib.tag("flat_gemm 1x1 dgrad + wgrad (bn backward on load)", 4.0 * M * C * C, 4.0 * h.numel() * _es(h))
+    _lib.call("nsg_bn_backward_conv1x1_dgrad_wgrad", _p(h), _p(dy), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(w), _p(dx), _p(dw),
+              _p(dh_colsum), _p(px), _p(pm), _p(pi), _p(pg), _p(pb), _p(prev_dgamma), _p(prev_dbeta), c_int64(M), c_int32(C),
+              c_int32(nsg_dtype(h.dtype)), _p(ws), c_size_t(nb), _stream())
+    return dx, dw, prev_dgamma, prev_dbeta
+
+
 def bn_backward_apply(x, dy, mean, invstd, gamma, dgamma, dbeta, relu_beta=None, dx_colsum=None):
     """The apply half of bn_backward with dgamma / dbeta given: dx."""
     _chk(x, "x", None); _chk(dy, "dy", x.dtype)

@@ -782,6 +782,20 @@ def test_resblock_1x1_conv_with_batchnorm_in_the_operand_staging(B, H, W, C):
     dxx_ref, _, _ = ops.bn_backward(x, None, dx, mean, invstd, gamma, relu_beta=beta)
     dxx = ops.bn_backward_apply(x, dx, mean, invstd, gamma, pdg_ref, pdb_ref, relu_beta=beta)
     assert torch.equal(dxx, dxx_ref)
+    # ... and with the conv's weight gradient in the same pass (C = 128): the same dx bit for bit (same operands, same MFMA
+    # chain), the same sums, and dw = what the weight-gradient kernel gives on (x, the bf16 dh) up to the order of the fp32 sums
+    assert ops.bn_backward_conv1x1_dgrad_wgrad_supported(torch.bfloat16, C) == (C == 128)
+    if C == 128:
+        cs2 = torch.empty(C, device=DEV)
+        dx_f, dw_f, pdg_f, pdb_f = ops.bn_backward_conv1x1_dgrad_wgrad(h, dy, m2, i2, g2, dg, db, w, (x, mean, invstd, gamma, beta), dh_colsum=cs2)
+        assert torch.equal(dx_f, dx)
+        _close(pdg_f.cpu(), pdg.cpu(), tol=1e-5, what="fused backward: dgamma of the BatchNorm in front")
+        _close(pdb_f.cpu(), pdb.cpu(), tol=1e-5, what="fused backward: dbeta of the BatchNorm in front")
+        assert float((cs2 - cs).abs().max()) <= 1e-5 * float(dh.float().abs().sum(dim=(0, 1, 2)).max()) + 1e-6    # (sums of a zero-mean tensor)
+        dw_sep = ops.bn_relu_conv1x1_wgrad(x, mean, invstd, gamma, beta, dh)
+        _close(dw_f.cpu(), dw_sep.cpu(), tol=2e-5, what="fused backward: dw vs the weight-gradient kernel on the stored dh")
+        dx_g, dw_g, _, _ = ops.bn_backward_conv1x1_dgrad_wgrad(h, dy, m2, i2, g2, dg, db, w, (x, mean, invstd, gamma, beta))
+        assert torch.equal(dx_g, dx_f) and torch.equal(dw_g, dw_f)      # run to run
 
 
 def test_batchnorm_eval():
