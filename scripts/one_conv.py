@@ -17,4 +17,13 @@ bias = torch.zeros(D, device=dev)
 for _ in range(iters):
     y = ops.conv_forward(d, x, wf, bias)
 torch.cuda.synchronize()
+if os.environ.get("TIME", "0") == "1":       # stand-alone timing (cold caches differ from the step's: an A/B tool, not a benchmark)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        y = ops.conv_forward(d, x, wf, bias)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print(f"{kind}: {us:.1f} us  {2.0 * y.numel() * D * k * k / (4 if tr else 1) / us * 1e-6:.1f} TFLOP/s")
 print("ok", float(y.float().abs().mean()))
