@@ -68,9 +68,9 @@ _SIGS = {
     "nsg_bn_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_size_t, _P]),
     "nsg_c1conv_bn_workspace_bytes": (c_size_t, [c_int32]),
     "nsg_c1conv_bn_relu_forward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_int32, _P, c_int32, c_int32, c_int32, c_int32,
-                                          c_int32, _P, c_size_t, _P]),
+                                          c_int32, _P, c_size_t, _P, _P]),
     "nsg_c1conv_bn_relu_backward": (None, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
-                                           c_size_t, _P]),
+                                           c_size_t, _P, _P]),
     "nsg_bn_relu_c1convt_supported": (c_int32, [c_int32, c_int32]),
     "nsg_bn_relu_c1convt_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "nsg_bn_relu_c1convt_forward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
@@ -145,7 +145,8 @@ def load():
     # experiment switches (diagnostics): NSG_GATHER_DMA=0|1, NSG_GATHER_TILE8=0|1 select gather_gemm staging / tile variants
     for env, sym in (("NSG_GATHER_DMA", "nsg_debug_set_gather_dma"), ("NSG_GATHER_TILE8", "nsg_debug_set_gather_tile8"),
                      ("NSG_PATCH_GEMM", "nsg_debug_set_patch_gemm"), ("NSG_PATCH_GRID", "nsg_debug_set_patch_grid"),
-                     ("NSG_WGRAD_STRIP", "nsg_debug_set_wgrad_strip"), ("NSG_PATCH_DIRECT", "nsg_debug_set_patch_direct")):
+                     ("NSG_WGRAD_STRIP", "nsg_debug_set_wgrad_strip"), ("NSG_PATCH_DIRECT", "nsg_debug_set_patch_direct"),
+                     ("NSG_C1_MOMENTS", "nsg_debug_set_c1_moments")):
         if env in os.environ:
             fn = getattr(lib, sym)
             fn.argtypes = [c_int32]

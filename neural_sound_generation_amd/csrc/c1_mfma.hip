@@ -499,6 +499,294 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The input layer by its TAP MOMENTS.  h[p][c] = b_c + sum_t w[c][t] x[p][t] is linear in the 16 patch values x[p][.] of an
+// output pixel, so everything the BatchNorm around it needs that is LINEAR or QUADRATIC in h follows from
+//     S[t] = sum_p x[p][t]   and   P[t][t'] = sum_p x[p][t] x[p][t']      (16 + 256 numbers, channel-independent, image only):
+//   forward    mean_c = b_c + w_c . S / M,   var_c = w_c^T (P / M - S S^T / M^2) w_c          (no pass over h at all)
+//   backward   dw[c][t] = sum_p x[p][t] dh[p][c] with dh = sc (g - dbeta / M - xhat dgamma / M) splits into
+//              sc ( G[t][c] - dbeta_c / M S[t] - dgamma_c / M invstd_c ( (P w_c)[t] + b_c S[t] - mean_c S[t] ) ),
+//              G[t][c] = sum_p x[p][t] g[p][c]  --  accumulated in the SAME pass over dy that forms dbeta = sum g and
+//              dgamma = sum g xhat: the tensor is read once instead of twice.
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(NSG_C1_MOMENTS == 16 * 17, "include/nsg.h");
+constexpr int MOM_N = 16 * 17;          // mom[t * 17 + u] = P[t][u] (u < 16), mom[t * 17 + 16] = S[t]
+constexpr int MOM_BLOCKS = 1024;
+
+// P and S on the matrix cores: for the 16 pixels a wave takes from a tile, X^T X with X = [pixel][16 taps | 1] is ONE MFMA whose A
+// and B operands are the same registers (lane = tap, 8 pixels per half-wave; lane 16 of B = the ones column that yields S),
+// issued three times on hi / lo bf16 splits (hi*hi + hi*lo + lo*hi: x to 2^-17).  Block = 4 waves = a 64-pixel tile.
+// partial[block][16][17]: row t = (P[t][0..15], S[t]).
+constexpr int MOM_ROW = 17;
+constexpr int MOM_GROUP = 4;         // tiles per iteration: their patch loads are in flight together (a single tile per iteration is
+                                     // one global-memory latency per 64 pixels: 69 us for the 2.6 M pixels of the headline shape)
+__global__ __launch_bounds__(256) void c1_tap_moments_kernel(const float *__restrict__ img, float *__restrict__ partial, const C1Geom g)
+{
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) float patch[2][MOM_GROUP][4 * PP];
+    __shared__ float red[4][16 * MOM_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5;
+    const int tap_off = ((n >> 2) & 3) * PP + (n & 3);
+    const unsigned tm = n < 16 ? 0xffffffffu : 0u;
+    const v4u tap_mask = {tm, tm, tm, tm}, ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // (bf16 1.0 pairs)
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ngroups = (g.ntiles + MOM_GROUP - 1) / MOM_GROUP;
+    float pr[MOM_GROUP][PatchRegs<NT>::N];
+    auto load_group = [&](int grp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < MOM_GROUP; ++q) {
+            const int tile = min(grp * MOM_GROUP + q, g.ntiles - 1);      // (a tile past the end: a valid patch, masked below)
+            int b, ly, ox0;
+            tile_coords(g, tile, b, ly, ox0);
+            patch_load<NT>(pr[q], img, g, b, ly, ox0, tid);
+        }
+    };
+    auto store_group = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < MOM_GROUP; ++q) patch_store<NT>(patch[buf][q], pr[q], tid);
+    };
+    int buf = 0;
+    if ((int)blockIdx.x < ngroups) { load_group(blockIdx.x); store_group(0); }
+    __syncthreads();
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, buf ^= 1) {
+        const int nxt = grp + gridDim.x;
+        if (nxt < ngroups) load_group(nxt);
+#pragma unroll
+        for (int q = 0; q < MOM_GROUP; ++q) {
+            const int tile = grp * MOM_GROUP + q;
+            int b, ly, ox0;
+            tile_coords(g, min(tile, g.ntiles - 1), b, ly, ox0);
+            const int npx = tile < g.ntiles ? min(TW, g.LW - ox0) : 0;
+            // this lane's 8 pixels: j = 16 wave + 8 hb + i; its tap = n (lanes 16..31: zero rows; lane 16 of B: ones)
+            bf16x8 ahi, alo, bhi, blo;
+            if (npx == TW) {                    // full tile (the common case): masks on the packed operands only
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = patch[buf][q][tap_off + 2 * (16 * wave + 8 * hb + i)];
+                split8(x, ahi, alo);
+                const v4u mh = __builtin_bit_cast(v4u, ahi) & tap_mask, ml = __builtin_bit_cast(v4u, alo) & tap_mask;
+                ahi = __builtin_bit_cast(bf16x8, mh);
+                alo = __builtin_bit_cast(bf16x8, ml);
+                bhi = __builtin_bit_cast(bf16x8, n == 16 ? ones : mh);
+                blo = __builtin_bit_cast(bf16x8, n == 16 ? v4u{0u, 0u, 0u, 0u} : ml);
+            } else {
+                // (masks as factors, not selects: a select lets hipcc sink each LDS read into its own branch, one LDS round trip at a time)
+                float x[8], one[8];
+                const float mt = n < 16 ? 1.f : 0.f, mo = n == 16 ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = 16 * wave + 8 * hb + i;
+                    const float mp = j < npx ? 1.f : 0.f;
+                    x[i] = patch[buf][q][tap_off + 2 * j] * (mt * mp);
+                    one[i] = mo * mp;
+                }
+                bf16x8 ohi, olo;
+                split8(x, ahi, alo);
+                split8(one, ohi, olo);             // (olo = 0)
+                bhi = n == 16 ? ohi : ahi;
+                blo = n == 16 ? olo : alo;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc, 0, 0, 0);
+        }
+        if (nxt < ngroups) store_group(buf ^ 1);
+        __syncthreads();
+    }
+    // rows (taps) of acc: register r < 8 of a lane in half hb is row acc_pixel(r, hb) < 16; column = lane n (< 17 used)
+    if (n < MOM_ROW) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[wave][acc_pixel(r, hb) * MOM_ROW + n] = acc[r];
+    }
+    __syncthreads();
+    for (int k = tid; k < 16 * MOM_ROW; k += NT)
+        partial[(size_t)blockIdx.x * 16 * MOM_ROW + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+}
+
+// mom[k] = sum over blocks (block order, double)
+__global__ __launch_bounds__(256) void c1_tap_moments_final_kernel(const float *__restrict__ partial, int nblocks, double *__restrict__ mom)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x * 32 + (tid >> 3), j = tid & 7;          // 8 lanes share a moment
+    double s = 0.0;
+    if (k < MOM_N) {
+        const int per = (nblocks + 7) / 8;
+        const int b0 = j * per, b1 = min(nblocks, b0 + per);
+        if (b1 > b0) s = nsg_strided_sum<double>(partial + (size_t)b0 * MOM_N + k, (size_t)MOM_N, b1 - b0);
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (j != 0 || k >= MOM_N) return;
+    s = 0.0;
+    for (int q = 0; q < 8; ++q) s += red[tid + q];
+    mom[k] = s;
+}
+
+__device__ __forceinline__ int mom_index(int t, int u) { return t * 17 + u; }      // P[t][u]
+__device__ __forceinline__ int mom_sum(int t) { return t * 17 + 16; }              // S[t]
+
+// one thread per channel: batch statistics of h from the tap moments (double), running statistics as nn.BatchNorm2d
+__global__ __launch_bounds__(64) void c1_stats_from_moments_kernel(const double *__restrict__ mom, const float *__restrict__ w,
+                                                                   const float *__restrict__ bias, int64_t M, int C, float eps, float momentum,
+                                                                   float *__restrict__ mean, float *__restrict__ invstd,
+                                                                   float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const double inv = 1.0 / (double)M;
+    double wv[16], m[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { wv[t] = (double)w[(size_t)c * 16 + t]; m[t] = mom[mom_sum(t)] * inv; }
+    double mu = bias ? (double)bias[c] : 0.0, var = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        mu += wv[t] * m[t];
+#pragma unroll
+        for (int u = t; u < 16; ++u) {
+            const double cov = mom[mom_index(t, u)] * inv - m[t] * m[u];
+            var += (t == u ? 1.0 : 2.0) * wv[t] * wv[u] * cov;
+        }
+    }
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    if (running_var) {
+        const double var_u = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+    }
+}
+
+// backward in ONE pass over dy: per block sums[2][C] = (sum g, invstd * sum g (h - mean)) and partial[c][17] = G^T (tap sums of
+// x g; entry 16 unused), g = dy where the ReLU passed (exact in bf16; the patch operand is rounded to bf16 as in every bf16 weight gradient).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void c1m_bwd_onepass_kernel(
+    const float *__restrict__ img, const float *__restrict__ w, const float *__restrict__ bias, const bf16_t *__restrict__ dy,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ sums, float *__restrict__ partial, const C1Geom g)
+{
+    constexpr int NT = 64 * NW, C = 32 * NW;
+    __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
+    __shared__ __attribute__((aligned(16))) bf16_t gbuf[2][TW * gpitch(C)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hb = lane >> 5, c = 32 * wave + n;
+    bf16x8 whi, wlo;
+    load_w_operand(w, c, hb, whi, wlo);
+    const float bs = bias ? bias[c] : 0.f;
+    const float mu = mean[c], is = invstd[c];
+    const float fs = is * gamma[c];
+    const float off = __builtin_fmaf(-mu, fs, beta[c]);
+    const unsigned tap_mask = n < 16 ? 0xffffffffu : 0u;
+    const int tap_off = ((n >> 2) & 3) * PP + (n & 3);
+    float s1 = 0.f, s2 = 0.f;
+    v16f dwacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+
+    int buf = 0;
+    float pr[PatchRegs<NT>::N];
+    v4f gr[4];
+    if ((int)blockIdx.x < g.ntiles) {
+        int b, ly, ox0;
+        tile_coords(g, blockIdx.x, b, ly, ox0);
+        patch_load<NT>(pr, img, g, b, ly, ox0, tid);
+        gtile_load<NW>(gr, dy, g, b, ly, ox0, min(TW, g.LW - ox0), tid);
+        patch_store<NT>(patch[0], pr, tid);
+        gtile_to_lds<NW>(gbuf[0], gr, tid);
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+        int b, ly, ox0;
+        tile_coords(g, tile, b, ly, ox0);
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) {
+            int nb, nly, nox0;
+            tile_coords(g, nxt, nb, nly, nox0);
+            patch_load<NT>(pr, img, g, nb, nly, nox0, tid);
+            gtile_load<NW>(gr, dy, g, nb, nly, nox0, min(TW, g.LW - nox0), tid);
+        }
+        const int npx = min(TW, g.LW - ox0);
+        auto body = [&](auto FULL) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if (!decltype(FULL)::value && 32 * mb >= npx) break;
+                const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
+                float d[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * mb + acc_pixel(r, hb);
+                    const float gv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
+                    bool pass = __builtin_fmaf(h[r], fs, off) > 0.f;
+                    if (!decltype(FULL)::value) pass = pass & (j < npx);
+                    d[r] = pass ? gv : 0.f;
+                    s1 += d[r];
+                    s2 = __builtin_fmaf(d[r], h[r] - mu, s2);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    v4u db, pa;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        db[i] = pack_bf16(d[8 * s + 2 * i], d[8 * s + 2 * i + 1]);      // exact: g is a bf16 value or zero
+                        const int j0 = 32 * mb + acc_pixel(8 * s + 2 * i, hb), j1 = 32 * mb + acc_pixel(8 * s + 2 * i + 1, hb);
+                        pa[i] = pack_bf16(patch[buf][tap_off + 2 * j0], patch[buf][tap_off + 2 * j1]) & tap_mask;
+                    }
+                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, db), dwacc, 0, 0, 0);
+                }
+            }
+        };
+        if (npx == TW) body(std::true_type{}); else body(std::false_type{});
+        if (nxt < g.ntiles) {
+            patch_store<NT>(patch[buf ^ 1], pr, tid);
+            gtile_to_lds<NW>(gbuf[buf ^ 1], gr, tid);
+        }
+        __syncthreads();
+    }
+    float *dst = partial + ((size_t)blockIdx.x * C + c) * 17;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dst[acc_pixel(r, hb)] = dwacc[r];
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hb == 0) {
+        dst[16] = 0.f;
+        float *sd = sums + (size_t)blockIdx.x * 2 * C;
+        sd[c] = s1;
+        sd[C + c] = s2 * is;
+    }
+}
+
+// dw[c][t] holds G[t][c] on entry; one thread per (c, t) finishes the weight gradient (double); dbias_c = sum_p dh[p][c]
+__global__ __launch_bounds__(256) void c1m_onepass_fixup_kernel(const double *__restrict__ mom, const float *__restrict__ w,
+                                                                const float *__restrict__ bias, const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                const float *__restrict__ dgamma, const float *__restrict__ dbeta, int64_t M,
+                                                                int C, float *__restrict__ dw, float *__restrict__ dbias)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= C * 16) return;
+    const int c = e >> 4, t = e & 15;
+    const double inv = 1.0 / (double)M;
+    const double is = (double)invstd[c], mu = (double)mean[c], b = bias ? (double)bias[c] : 0.0;
+    const double sc = (double)gamma[c] * is;
+    double pw = 0.0;                     // (P w_c)[t]
+#pragma unroll
+    for (int u = 0; u < 16; ++u) pw += mom[mom_index(t, u)] * (double)w[(size_t)c * 16 + u];
+    const double St = mom[mom_sum(t)];
+    const double X = is * (pw + (b - mu) * St);               // sum_p x[p][t] xhat[p][c]
+    const double G = (double)dw[e];
+    dw[e] = (float)(sc * (G - (double)dbeta[c] * inv * St - (double)dgamma[c] * inv * X));
+    if (t == 0 && dbias) {               // sc (sum g - dbeta - dgamma / M sum xhat), sum xhat = invstd (sum h - M mean)
+        double sh = (double)M * b;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sh += (double)w[(size_t)c * 16 + u] * mom[mom_sum(u)];
+        dbias[c] = (float)(-sc * (double)dgamma[c] * inv * is * (sh - (double)M * mu));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The output layer's forward: dots[m][t] = sum_c max(fma(u[m][c], fs[c], off[c]), 0) * w[c][t], m over all B*LH*LW pixels
 // (the BatchNorm apply + ReLU happen on the operand's way into the MFMA: the activated tensor is never stored); the
 // 16 tap products of a pixel are then scattered onto the image by col2im_c1_kernel (conv_api.hip) with bias and tanh.
@@ -644,6 +932,49 @@ int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias
     NSG_C1M_DISPATCH2(c1m_bwd_wgrad_kernel, false, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, dgamma, dbeta,
                       inv_m, partial, (bf16_t *)nullptr, g)
     return nsg_check_launch("c1m_bwd_wgrad_kernel");
+}
+
+// ---- the input layer by its tap moments ----
+size_t nsg_c1m_moments_bytes() { return nsg_align_up((size_t)MOM_BLOCKS * MOM_N * sizeof(float), 256) + nsg_align_up((size_t)MOM_N * sizeof(double), 256); }
+
+// ws: nsg_c1m_moments_bytes() bytes; the moments (NSG_C1_MOMENTS doubles) go to mom_dst, or into ws when that is null; *mom_out = where
+int nsg_launch_c1m_moments(const float *img, int B, int LH, int LW, int HH, int WW, void *ws, double *mom_dst, const double **mom_out, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, HH, WW, 32);
+    float *partial = reinterpret_cast<float *>(ws);
+    double *mom = mom_dst ? mom_dst : reinterpret_cast<double *>(reinterpret_cast<char *>(ws) + nsg_align_up((size_t)MOM_BLOCKS * MOM_N * sizeof(float), 256));
+    int64_t blocks = (g.ntiles + MOM_GROUP - 1) / MOM_GROUP;
+    if (blocks > MOM_BLOCKS) blocks = MOM_BLOCKS;
+    hipLaunchKernelGGL(c1_tap_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, partial, g);
+    hipLaunchKernelGGL(c1_tap_moments_final_kernel, dim3((MOM_N + 31) / 32), dim3(256), 0, s, partial, (int)blocks, mom);
+    *mom_out = mom;
+    return nsg_check_launch("c1_tap_moments_kernel");
+}
+
+int nsg_launch_c1m_stats_from_moments(const double *mom, const float *w, const float *bias, int64_t M, int C, float eps, float momentum,
+                                      float *mean, float *invstd, float *running_mean, float *running_var, hipStream_t s)
+{
+    hipLaunchKernelGGL(c1_stats_from_moments_kernel, dim3((C + 63) / 64), dim3(64), 0, s, mom, w, bias, M, C, eps, momentum, mean, invstd,
+                       running_mean, running_var);
+    return nsg_check_launch("c1_stats_from_moments_kernel");
+}
+
+int nsg_launch_c1m_bwd_onepass(const float *img, const float *w, const float *bias, const void *dy, const float *mean, const float *invstd,
+                               const float *gamma, const float *beta, float *sums, float *partial17, int blocks, int B, int LH, int LW,
+                               int HH, int WW, int C, hipStream_t s)
+{
+    const C1Geom g = make_geom(B, LH, LW, HH, WW, C);
+    NSG_C1M_DISPATCH(c1m_bwd_onepass_kernel, img, w, bias, reinterpret_cast<const bf16_t *>(dy), mean, invstd, gamma, beta, sums, partial17, g)
+    return nsg_check_launch("c1m_bwd_onepass_kernel");
+}
+
+int nsg_launch_c1m_onepass_fixup(const double *mom, const float *w, const float *bias, const float *mean, const float *invstd,
+                                 const float *gamma, const float *dgamma, const float *dbeta, int64_t M, int C, float *dw, float *dbias,
+                                 hipStream_t s)
+{
+    hipLaunchKernelGGL(c1m_onepass_fixup_kernel, dim3((C * 16 + 255) / 256), dim3(256), 0, s, mom, w, bias, mean, invstd, gamma, dgamma, dbeta,
+                       M, C, dw, dbias);
+    return nsg_check_launch("c1m_onepass_fixup_kernel");
 }
 
 // ---- the output layer BatchNorm -> ReLU -> ConvTranspose2d(C, 1, 4, 2, 1) (conv_api.hip: nsg_bn_relu_c1convt_*) ----

@@ -653,6 +653,20 @@ int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias
                              const float *gamma, const float *beta, const float *dgamma, const float *dbeta, float inv_m, float *partial,
                              int blocks, int B, int LH, int LW, int HH, int WW, int C, hipStream_t s);
 
+// ... and the input layer by its tap moments (c1_mfma.hip): statistics without a pass over h, backward in one pass over dy
+size_t nsg_c1m_moments_bytes();
+int nsg_launch_c1m_moments(const float *img, int B, int LH, int LW, int HH, int WW, void *ws, double *mom_dst, const double **mom_out, hipStream_t s);
+int nsg_launch_c1m_stats_from_moments(const double *mom, const float *w, const float *bias, int64_t M, int C, float eps, float momentum,
+                                      float *mean, float *invstd, float *running_mean, float *running_var, hipStream_t s);
+int nsg_launch_c1m_bwd_onepass(const float *img, const float *w, const float *bias, const void *dy, const float *mean, const float *invstd,
+                               const float *gamma, const float *beta, float *sums, float *partial17, int blocks, int B, int LH, int LW,
+                               int HH, int WW, int C, hipStream_t s);
+int nsg_launch_c1m_onepass_fixup(const double *mom, const float *w, const float *bias, const float *mean, const float *invstd,
+                                 const float *gamma, const float *dgamma, const float *dbeta, int64_t M, int C, float *dw, float *dbias,
+                                 hipStream_t s);
+int g_c1_moments = 1;     // nsg_debug_set_c1_moments: 0 = the two-pass forms (statistics pass over h; sums pass + gradient pass over dy)
+extern "C" NSG_API void nsg_debug_set_c1_moments(int on) { g_c1_moments = on; }
+
 namespace {
 constexpr int FUSED_BLOCKS = 1024;      // = bn.hip's MAX_SLABS (bn_bwd_final_kernel) and WGRAD_BLOCKS
 size_t fused_tiles_bytes(int C) { return nsg_align_up(nsg_bn_tiles_bytes(2 * FUSED_BLOCKS, C), 256); }
@@ -672,14 +686,14 @@ size_t nsg_c1conv_bn_workspace_bytes(int32_t C)
 {
     if (C <= 0) return 0;
     const size_t fwd = fused_tiles_bytes(C);
-    const size_t bwd = fused_sums_bytes(C) + nsg_c1_stencil_wgrad_workspace_bytes(C);
-    return fwd > bwd ? fwd : bwd;
+    const size_t bwd = fused_sums_bytes(C) + nsg_align_up(nsg_c1_stencil_wgrad_workspace_bytes(C), 256);
+    return (fwd > bwd ? fwd : bwd) + nsg_c1m_moments_bytes();       // (the moments sit behind the larger of the two)
 }
 
 int nsg_c1conv_bn_relu_forward(const float *img, const float *w, const float *bias, const float *gamma, const float *beta, float *mean,
                                float *invstd, float *running_mean, float *running_var, float eps, float momentum, int32_t training,
                                void *y, int32_t y_dtype, int32_t B, int32_t H, int32_t W, int32_t C, void *workspace,
-                               size_t workspace_bytes, void *stream)
+                               size_t workspace_bytes, double *moments, void *stream)
 {
     NSG_REQUIRE(img && w && gamma && beta && mean && invstd && y, NSG_E_INVALID, "nsg_c1conv_bn_relu_forward: null pointer");
     NSG_REQUIRE(y_dtype == NSG_F32 || y_dtype == NSG_BF16, NSG_E_INVALID, "nsg_c1conv_bn_relu_forward: y_dtype must be NSG_F32 or NSG_BF16");
@@ -695,6 +709,15 @@ int nsg_c1conv_bn_relu_forward(const float *img, const float *w, const float *bi
         NSG_REQUIRE(workspace && workspace_bytes >= nsg_c1conv_bn_workspace_bytes(C), NSG_E_WORKSPACE, "nsg_c1conv_bn_relu_forward: workspace too small");
         const int blocks = g.ntiles < 2 * FUSED_BLOCKS ? g.ntiles : 2 * FUSED_BLOCKS;
         float *tiles = reinterpret_cast<float *>(workspace);
+        if (mfma && g_c1_moments) {      // statistics of h from the image's tap moments: no pass over h
+            const double *mom = nullptr;
+            rc = nsg_launch_c1m_moments(img, B, g.LH, g.LW, H, W, reinterpret_cast<char *>(workspace) + nsg_c1conv_bn_workspace_bytes(C) - nsg_c1m_moments_bytes(), moments, &mom, s);
+            if (rc) return rc;
+            rc = nsg_launch_c1m_stats_from_moments(mom, w, bias, (int64_t)B * g.LH * g.LW, C, eps, momentum, mean, invstd, running_mean, running_var, s);
+            if (rc) return rc;
+            const int ablocks = g.ntiles < 2048 ? g.ntiles : 2048;
+            return nsg_launch_c1m_apply(img, w, bias, mean, invstd, gamma, beta, y, ablocks, B, g.LH, g.LW, H, W, C, s);
+        }
         if (mfma) {
             rc = nsg_launch_c1m_stats(img, w, bias, tiles, blocks, B, g.LH, g.LW, H, W, C, s);
         } else {
@@ -717,7 +740,7 @@ int nsg_c1conv_bn_relu_forward(const float *img, const float *w, const float *bi
 int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const float *bias, const float *gamma, const float *beta,
                                 const float *mean, const float *invstd, const void *dy, int32_t dy_dtype, float *dw, float *dbias,
                                 float *dgamma, float *dbeta, int32_t B, int32_t H, int32_t W, int32_t C, void *workspace,
-                                size_t workspace_bytes, void *stream)
+                                size_t workspace_bytes, const double *moments, void *stream)
 {
     NSG_REQUIRE(img && w && gamma && beta && mean && invstd && dy && dw && dgamma && dbeta, NSG_E_INVALID, "nsg_c1conv_bn_relu_backward: null pointer");
     NSG_REQUIRE(dy_dtype == NSG_F32 || dy_dtype == NSG_BF16, NSG_E_INVALID, "nsg_c1conv_bn_relu_backward: dy_dtype must be NSG_F32 or NSG_BF16");
@@ -731,6 +754,22 @@ int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const float *b
     float *sums = reinterpret_cast<float *>(workspace);
     float *partial17 = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + fused_sums_bytes(C));
     const float inv_m = 1.f / (float)((int64_t)B * g.LH * g.LW);
+    if (dy_dtype == NSG_BF16 && nsg_c1m_supported(C) && g_c1_moments) {      // one pass over dy (c1_mfma.hip: "by its tap moments")
+        const double *mom = moments;
+        const int64_t M = (int64_t)B * g.LH * g.LW;
+        if (!mom) {
+            rc = nsg_launch_c1m_moments(img, B, g.LH, g.LW, H, W, reinterpret_cast<char *>(workspace) + nsg_c1conv_bn_workspace_bytes(C) - nsg_c1m_moments_bytes(), nullptr, &mom, s);
+            if (rc) return rc;
+        }
+        rc = nsg_launch_c1m_bwd_onepass(img, w, bias, dy, mean, invstd, gamma, beta, sums, partial17, blocks, B, g.LH, g.LW, H, W, C, s);
+        if (rc) return rc;
+        rc = nsg_launch_bn_bwd_final(sums, blocks, C, dgamma, dbeta, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(c1_stencil_wgrad_final_kernel, dim3((C * 17 + 31) / 32), dim3(256), 0, s, partial17, blocks, C, dw, (float *)nullptr);
+        rc = nsg_check_launch("c1_stencil_wgrad_final_kernel");
+        if (rc) return rc;
+        return nsg_launch_c1m_onepass_fixup(mom, w, bias, mean, invstd, gamma, dgamma, dbeta, M, C, dw, dbias, s);
+    }
     if (dy_dtype == NSG_BF16 && nsg_c1m_supported(C)) {     // the forward's choice for bf16 tensors: the same h, the same ReLU decisions
         rc = nsg_launch_c1m_bwd_sums(img, w, bias, dy, mean, invstd, gamma, beta, sums, blocks, B, g.LH, g.LW, H, W, C, s);
         if (rc) return rc;

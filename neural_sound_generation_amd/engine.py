@@ -229,11 +229,13 @@ def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32, pa
     d0 = ops.conv_desc(B, H, W, 1, D, 4, 2, 1, dtype=dtype)
     pk = packs if packs is not None else {}
     wf0, _ = pk["conv0"] if packs is not None else ops.pack_weights(d0, P.conv0.weight, want_dgrad=False)
+    mom0 = None
     if FUSED_C1_LAYER and D % 4 == 0 and D <= 1024 and H % 2 == 0 and W % 2 == 0:
         h0 = None                                    # never materialised; the backward recomputes it from x
         if training:
+            mom0 = torch.empty(ops.C1_MOMENTS, dtype=torch.float64, device=x.device)     # the image's tap moments: forward statistics, backward
             a0, m0, i0 = ops.c1conv_bn_relu_forward(x, P.conv0.weight, P.conv0.bias, P.bn0.weight, P.bn0.bias, P.bn0.running_mean,
-                                                    P.bn0.running_var, training=True, out_dtype=dtype)
+                                                    P.bn0.running_var, training=True, out_dtype=dtype, moments=mom0)
             _bump(P.bn0)
         else:
             m0, i0 = ops.bn_eval_stats(P.bn0.running_mean, P.bn0.running_var)
@@ -247,14 +249,14 @@ def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32, pa
     e3 = ops.conv_forward(d3, a0, wf3, P.conv3.bias, flags=NSG_RELU_OUT)     # stored ReLU'd: its only consumer is a ResBlock
     r4, s4 = resblock_forward(e3, P.res4, training, relu_out=True, packs=pk.get("res4"))
     ze, s5 = resblock_forward(r4, P.res5, training, out_dtype=torch.float32, packs=pk.get("res5"))
-    saved = (x, h0, a0, m0, i0, d0, d3, wd3, s4, s5)
+    saved = (x, h0, a0, m0, i0, d0, d3, wd3, s4, s5, mom0)
     return ze, saved
 
 
 def encoder_backward(dze, saved, P: EncoderParams, gout=None):
     """Gradients of every encoder parameter, in state_dict order (input gets none: it is data).
     dze must have the encoder's compute dtype.  gout: optional list of 22 preallocated tensors to write into."""
-    x, h0, a0, m0, i0, d0, d3, wd3, s4, s5 = saved
+    x, h0, a0, m0, i0, d0, d3, wd3, s4, s5, mom0 = saved
     dze = ops.convert(dze, a0.dtype)
     o = gout if gout is not None else [None] * 22
     dr4, g5 = resblock_backward(dze, s5, P.res5, gout=o[14:22] if gout is not None else None)
@@ -263,7 +265,7 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
     da0 = ops.conv_dgrad(d3, de3, wd3)
     if h0 is None:      # fused input layer: BatchNorm backward and the weight gradient straight from (x, da0)
         dw0, db0, dg0, dbe0 = ops.c1conv_bn_relu_backward(x, P.conv0.weight, P.conv0.bias, P.bn0.weight, P.bn0.bias, m0, i0, da0,
-                                                          dw=o[0], dbias=o[1], dgamma=o[2], dbeta=o[3])
+                                                          dw=o[0], dbias=o[1], dgamma=o[2], dbeta=o[3], moments=mom0)
         return [dw0, db0, dg0, dbe0, dw3, db3] + g4 + g5
     db0 = o[1] if o[1] is not None else torch.empty(h0.shape[-1], dtype=torch.float32, device=h0.device)
     dh0, dg0, dbe0 = ops.bn_backward(h0, None, da0, m0, i0, P.bn0.weight, dgamma=o[2], dbeta=o[3], dx_colsum=db0, relu_beta=P.bn0.bias)

@@ -470,12 +470,18 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
 # ------------------------------------------------------------------------------------------------
 # encoder.0-2 as one operator: Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU   (src/models.py:165-167)
 # ------------------------------------------------------------------------------------------------
+C1_MOMENTS = 272      # include/nsg.h: NSG_C1_MOMENTS
+
+
 def c1conv_bn_relu_forward(img, w, bias, gamma, beta, running_mean=None, running_var=None, training=True, eps=1e-5, momentum=0.1,
-                           mean=None, invstd=None, out_dtype=torch.float32):
+                           mean=None, invstd=None, out_dtype=torch.float32, moments=None):
     """img fp32 (B, H, W) or (B, H, W, 1); w the Conv2d parameter (C, 1, 4, 4) fp32.  Returns (y NHWC (B, H/2, W/2, C) of
     out_dtype, mean, invstd).  training=False: mean / invstd must be given (bn_eval_stats).  The conv output itself is
-    never stored (nsg.h: nsg_c1conv_bn_relu_forward)."""
+    never stored (nsg.h: nsg_c1conv_bn_relu_forward).  moments: optional float64 tensor of C1_MOMENTS elements that receives the
+    image's tap moments in training mode (hand it to c1conv_bn_relu_backward: it then skips recomputing them)."""
     _chk(img, "img", torch.float32); _chk(w, "w", torch.float32)
+    if moments is not None and (moments.dtype != torch.float64 or moments.numel() != C1_MOMENTS or not moments.is_contiguous()):
+        raise ValueError("c1conv_bn_relu_forward: moments must be a contiguous float64 tensor of C1_MOMENTS elements")
     B, H, W = img.shape[0], img.shape[1], img.shape[2]
     C = w.shape[0]
     if w.numel() != C * 16 or img.numel() != B * H * W:
@@ -491,12 +497,13 @@ def c1conv_bn_relu_forward(img, w, bias, gamma, beta, running_mean=None, running
     _lib.tag("c1conv_bn_relu_forward (fused input layer)", 2.0 * 16 * y.numel() * (2 if training else 1), 4.0 * img.numel() * (2 if training else 1) + y.numel() * _es(y))
     _lib.call("nsg_c1conv_bn_relu_forward", _p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(running_mean),
               _p(running_var), c_float(eps), c_float(momentum), c_int32(1 if training else 0), _p(y), c_int32(nsg_dtype(out_dtype)),
-              c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws), c_size_t(nb), _stream())
+              c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws), c_size_t(nb), _p(moments), _stream())
     return y, mean, invstd
 
 
-def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None, dbias=None, dgamma=None, dbeta=None):
-    """Parameter gradients (dw (C, 1, 4, 4), dbias, dgamma, dbeta) of the fused layer from dy (B, H/2, W/2, C)."""
+def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None, dbias=None, dgamma=None, dbeta=None, moments=None):
+    """Parameter gradients (dw (C, 1, 4, 4), dbias, dgamma, dbeta) of the fused layer from dy (B, H/2, W/2, C).
+    moments: what the training forward wrote (same image), or None (recomputed)."""
     _chk(img, "img", torch.float32); _chk(w, "w", torch.float32); _chk(dy, "dy", None)
     B, H, W = img.shape[0], img.shape[1], img.shape[2]
     C = w.shape[0]
@@ -509,10 +516,11 @@ def c1conv_bn_relu_backward(img, w, bias, gamma, beta, mean, invstd, dy, dw=None
     dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
     nb = _lib.query("nsg_c1conv_bn_workspace_bytes", c_int32(C))
     ws = WS.get(nb, dev)
-    _lib.tag("c1conv_bn_relu_backward (fused input layer)", 2.0 * 16 * dy.numel() * 3, 2.0 * (4.0 * img.numel() + dy.numel() * _es(dy)))
+    passes = 1.0 if dy.dtype == torch.bfloat16 else 2.0          # bf16: one pass over dy (tap moments), fp32: sums pass + gradient pass
+    _lib.tag("c1conv_bn_relu_backward (fused input layer)", 2.0 * 16 * dy.numel() * 3, passes * (4.0 * img.numel() + dy.numel() * _es(dy)))
     _lib.call("nsg_c1conv_bn_relu_backward", _p(img), _p(w), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dy),
               c_int32(nsg_dtype(dy.dtype)), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C),
-              _p(ws), c_size_t(nb), _stream())
+              _p(ws), c_size_t(nb), _p(moments), _stream())
     return dw, dbias, dgamma, dbeta
 
 

@@ -3,6 +3,7 @@ CPU PyTorch fp32 for floating-point kernels -- the same ATen ops the reference c
 inputs, plus the committed golden vectors.  Tolerances are written at each comparison."""
 import os
 
+import ctypes
 import numpy as np
 import pytest
 import torch
@@ -644,6 +645,25 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
     _close(dbt.cpu(), gbe, tol=tol, what="fused layer dbeta")
     # the conv bias sits in front of a BatchNorm: its true gradient is zero up to rounding
     assert float(dbias.abs().max()) <= 1e-4 * float(dyg.float().abs().sum(dim=(0, 1, 2)).max()) + 1e-6
+
+    if bf and ops.bn_relu_c1convt_supported(torch.bfloat16, C):
+        # the bf16 layer works from the image's tap moments (statistics without a pass over h, backward in one pass over dy):
+        # against the two-pass forms of the same kernels (nsg_debug_set_c1_moments(0)): statistics to 1e-5, weight gradient to 1e-2
+        # (the two-pass weight gradient rounds dh to bf16, the one-pass form multiplies the exact bf16 dy)
+        from neural_sound_generation_amd import _lib
+        lib = _lib.load()
+        lib.nsg_debug_set_c1_moments.argtypes = [ctypes.c_int32]
+        lib.nsg_debug_set_c1_moments(0)
+        try:
+            y2, mean2, invstd2 = ops.c1conv_bn_relu_forward(imgg, wg, bg, gag, beg, training=True, out_dtype=dt)
+            dw2p, dbias2p, dgm2p, dbt2p = ops.c1conv_bn_relu_backward(imgg, wg, bg, gag, beg, mean, invstd, dyg)
+        finally:
+            lib.nsg_debug_set_c1_moments(1)
+        np.testing.assert_allclose(mean.cpu().numpy(), mean2.cpu().numpy(), rtol=1e-5, atol=5e-6)      # (h itself carries 2^-17 per product
+        np.testing.assert_allclose(invstd.cpu().numpy(), invstd2.cpu().numpy(), rtol=1e-5)             #  in the two-pass form)
+        _close(dgm.cpu(), dgm2p.cpu(), tol=1e-5, what="one-pass dgamma vs two-pass")
+        _close(dbt.cpu(), dbt2p.cpu(), tol=1e-5, what="one-pass dbeta vs two-pass")
+        _close(dw.cpu(), dw2p.cpu(), tol=1e-2, what="one-pass dw vs two-pass")
 
     # eval mode: statistics are inputs
     em, ei = ops.bn_eval_stats(rmg, rvg)
