@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__rest
     const int c0 = blockIdx.x * 4;
     v4f ms[PER], qs[PER];
     float ns[PER];
+    float rm0[4], rv0[4];        // the running statistics travel with the partials (read by every thread: no lane condition on a load)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int cc = c0 + e < C ? c0 + e : C - 1;
+        rm0[e] = running_mean ? running_mean[cc] : 0.f;
+        rv0[e] = running_var ? running_var[cc] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int s = tid + 256 * i;
@@ -136,10 +143,10 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__rest
             const double var_b = m2 / (double)M;
             mean[c] = (float)mu[e];
             invstd[c] = (float)(1.0 / sqrt(var_b + (double)eps));
-            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu[e];
+            if (running_mean) running_mean[c] = (1.f - momentum) * rm0[e] + momentum * (float)mu[e];
             if (running_var) {
                 const double var_u = M > 1 ? m2 / (double)(M - 1) : var_b;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+                running_var[c] = (1.f - momentum) * rv0[e] + momentum * (float)var_u;
             }
         }
     }
@@ -186,11 +193,18 @@ __global__ __launch_bounds__(256) void bn_stats_tiles_final_kernel(const double 
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const float rm0 = running_mean ? running_mean[c] : 0.f, rv0 = running_var ? running_var[c] : 0.f;     // (in flight with the chunks)
     double N = 0.0, S = 0.0, Q = 0.0;
-    for (int k = 0; k < TILE_CHUNKS; ++k) {
-        N += chunks[(size_t)k * 3 * C + c];
-        S += chunks[(size_t)k * 3 * C + C + c];
-        Q += chunks[(size_t)k * 3 * C + 2 * C + c];
+    for (int k0 = 0; k0 < TILE_CHUNKS; k0 += 16) {        // 48 loads in flight, added in chunk order
+        double n[16], sv[16], q[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            n[k] = chunks[(size_t)(k0 + k) * 3 * C + c];
+            sv[k] = chunks[(size_t)(k0 + k) * 3 * C + C + c];
+            q[k] = chunks[(size_t)(k0 + k) * 3 * C + 2 * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { N += n[k]; S += sv[k]; Q += q[k]; }
     }
     const double mu = S / N;
     double m2 = Q - S * S / N;
@@ -198,10 +212,10 @@ __global__ __launch_bounds__(256) void bn_stats_tiles_final_kernel(const double 
     const double var_b = m2 / (double)M;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var_b + (double)eps));
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    if (running_mean) running_mean[c] = (1.f - momentum) * rm0 + momentum * (float)mu;
     if (running_var) {
         const double var_u = M > 1 ? m2 / (double)(M - 1) : var_b;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+        running_var[c] = (1.f - momentum) * rv0 + momentum * (float)var_u;
     }
 }
 

@@ -74,10 +74,9 @@ __global__ __launch_bounds__(256) void seg_scan_blk_kernel(int *__restrict__ blo
         const int s0 = b0 + seg * per, s1 = min(b0 + span, s0 + per);
         int c[SEG_SCAN_MAX];
 #pragma unroll
-        for (int j = 0; j < SEG_SCAN_MAX; ++j) {          // unconditional (clamped) loads, then the select: no branch per load
-            const int v = blockcnt[(size_t)min(s0 + j, nb - 1) * K + (live ? k : 0)];
-            c[j] = (live && s0 + j < s1) ? v : 0;
-        }
+        for (int j = 0; j < SEG_SCAN_MAX; ++j) c[j] = blockcnt[(size_t)min(s0 + j, nb - 1) * K + (live ? k : 0)];     // unconditional, clamped
+#pragma unroll
+        for (int j = 0; j < SEG_SCAN_MAX; ++j) c[j] &= -(int)(live && s0 + j < s1);     // (a select here lets hipcc sink every load into its own branch)
         int sum = 0;
 #pragma unroll
         for (int j = 0; j < SEG_SCAN_MAX; ++j) sum += c[j];
