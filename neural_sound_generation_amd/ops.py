@@ -48,13 +48,19 @@ def _chk(t, name, dtype=torch.float32):
 
 
 class Workspace:
-    """One growing scratch buffer per device; kernels on one stream run in order, so reuse is safe."""
+    """One growing scratch buffer per (device, stream): kernels on one stream run in order, so reuse is safe; a second stream
+    (engine.py runs the weight gradients on one) gets a buffer of its own."""
 
     def __init__(self):
         self._buf = {}
 
+    @staticmethod
+    def _key(device):
+        sid = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        return (device.type, device.index, sid)
+
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = self._key(device)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -62,9 +68,10 @@ class Workspace:
         return buf
 
     def current(self, device):
-        """The buffer get() hands out for `device` right now (None before first use).  Growth REPLACES it; whoever baked
-        its address into a HIP graph keeps a reference to this tensor so the address stays theirs (FusedTrainStep.capture)."""
-        return self._buf.get((device.type, device.index))
+        """The buffer get() hands out for `device` on the current stream right now (None before first use).  Growth REPLACES
+        it; whoever baked its address into a HIP graph keeps a reference to this tensor so the address stays theirs
+        (FusedTrainStep.capture)."""
+        return self._buf.get(self._key(device))
 
 
 WS = Workspace()
