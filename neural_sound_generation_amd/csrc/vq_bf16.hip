@@ -41,7 +41,10 @@ __device__ __forceinline__ void split8(const v4f a, const v4f b, bf16x8 &hi, bf1
 
 // Block = 4 waves = 128 rows of x (32 per wave, held as MFMA A fragments hi/lo); the pre-split codebook streams through
 // double-buffered LDS in tiles of 32 codes; the (N, K) matrix is never materialised.
-template <int NKS>   // k-steps of 16 channels: DP = 16 * NKS >= D
+// HAS_X2 = false: no |x|^2 term (it changes no argmin; only the reported distances need it): 16 registers fewer, which at
+// D = 128 is the difference between two and three blocks per CU (the kernel alternates between an HBM phase -- its rows in, the
+// picked codes out -- and an MFMA phase, and only other blocks on the CU overlap the two)
+template <int NKS, bool HAS_X2>   // k-steps of 16 channels: DP = 16 * NKS >= D
 __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__restrict__ x, const bf16_t *__restrict__ ehi,
                                                                 const bf16_t *__restrict__ elo, const float *__restrict__ e,
                                                                 const float *__restrict__ x2, const float *__restrict__ c2,
@@ -78,11 +81,13 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
             split8(a, b, ahi[s], alo[s]);
         }
     }
-    float x2v[16];
+    float x2v[HAS_X2 ? 16 : 1];
+    if (HAS_X2) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        x2v[r] = (x2 && row < N) ? x2[row] : 0.f;     // x2 == null: the search runs on c2 - 2 x.e (the row constant changes no argmin)
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            x2v[r] = row < N ? x2[row] : 0.f;
+        }
     }
     float best[16];
     int bidx[16];
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float dist = __fmaf_rn(-2.0f, acc[r], __fadd_rn(c2v, x2v[r]));
+            const float dist = HAS_X2 ? __fmaf_rn(-2.0f, acc[r], __fadd_rn(c2v, x2v[r])) : __fmaf_rn(-2.0f, acc[r], c2v);
             if (dist < best[r]) { best[r] = dist; bidx[r] = code; }
         }
         if (ct + 1 < ntiles) lstore(cur ^ 1);
@@ -207,10 +212,12 @@ int launch(const float *x, const bf16_t *ehi, const bf16_t *elo, const float *e,
     if (nb > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "vq_forward_bf16x3: too many rows");
     static LdsOptIn once;
     if (lds > 65536 - 1024) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&vq_forward_bf16x3_kernel<NKS>)}, lds, "vq_forward_bf16x3");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&vq_forward_bf16x3_kernel<NKS, true>),
+                                             reinterpret_cast<const void *>(&vq_forward_bf16x3_kernel<NKS, false>)}, lds, "vq_forward_bf16x3");
         if (rc != NSG_OK) return rc;
     }
-    hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
+    if (x2) hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS, true>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
+    else    hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS, false>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
     return nsg_check_launch("vq_forward_bf16x3_kernel");
 }
 
