@@ -22,7 +22,7 @@ struct SlabGeom {
 inline SlabGeom slab_geom(int64_t M)
 {
     SlabGeom g;
-    int64_t n = nsg_cdiv(M, 256);  // >= 256 rows per slab
+    int64_t n = nsg_cdiv(M, 64);   // >= 64 rows per slab (256 left 320 blocks for the 82 K rows of BASELINE configs[3]: 1.25 per CU)
     if (n > MAX_SLABS) n = MAX_SLABS;
     if (n < 1) n = 1;
     g.rows = (int)nsg_cdiv(M, n);
