@@ -284,7 +284,8 @@ NSG_API int nsg_c1conv_bn_relu_forward(const float *img, const float *w, const f
 /* Gradients of the layer's parameters from dy = dL/dy (the image is data: no input gradient):
  * dw [C][16], dbias [C] or NULL, dgamma [C], dbeta [C], all overwritten; mean / invstd as the forward left them.
  * moments (both calls; NULL allowed): NSG_C1_MOMENTS doubles = the image's tap moments S[t] = sum_p x[p][t] and
- * P[t][u] = sum_p x[p][t] x[p][u] over the 16 patch values of every output pixel.  The bf16 layer takes its batch statistics
+ * P[t][u] = sum_p x[p][t] x[p][u] over the 16 patch values of every output pixel (stored for values shifted by a constant,
+ * the last entry: conditioning).  The bf16 layer takes its batch statistics
  * and its weight gradient from them (one pass over dy instead of two).  The training forward writes them when the pointer is
  * not NULL; the backward reads them when given and recomputes them from the image otherwise. */
 NSG_API int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const float *bias, const float *gamma,
@@ -292,7 +293,7 @@ NSG_API int nsg_c1conv_bn_relu_backward(const float *img, const float *w, const 
                                         int32_t dy_dtype, float *dw, float *dbias, float *dgamma, float *dbeta, int32_t B,
                                         int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes,
                                         const double *moments, void *stream);
-#define NSG_C1_MOMENTS 272
+#define NSG_C1_MOMENTS 273
 
 /* ---------------------------------------------------------------------------------------------
  * The single-channel OUTPUT layer with the BatchNorm in front of it, as one operator     src/models.py:180-183

@@ -508,8 +508,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
 //              G[t][c] = sum_p x[p][t] g[p][c]  --  accumulated in the SAME pass over dy that forms dbeta = sum g and
 //              dgamma = sum g xhat: the tensor is read once instead of twice.
 // ---------------------------------------------------------------------------------------------------------------
-static_assert(NSG_C1_MOMENTS == 16 * 17, "include/nsg.h");
-constexpr int MOM_N = 16 * 17;          // mom[t * 17 + u] = P[t][u] (u < 16), mom[t * 17 + 16] = S[t]
+// The moments are taken of the SHIFTED values x' = x - shift (every patch entry, padding included: an exact change of variables),
+// shift = the mean of a fixed sample of the image, identical in every block: P' / M is then of the order of the covariance and
+// the quadratic forms below lose nothing to a large image mean (var = w^T (P/M - S S^T / M^2) w cancels badly when mean^2 >> var).
+static_assert(NSG_C1_MOMENTS == 16 * 17 + 1, "include/nsg.h");
+constexpr int MOM_N = 16 * 17;          // mom[t * 17 + u] = P'[t][u] (u < 16), mom[t * 17 + 16] = S'[t];  mom[MOM_N] = shift
+constexpr int MOM_SAMPLE = 256;
+
+// the shift: mean of MOM_SAMPLE image values at a fixed stride, summed in a fixed tree -- the same number in every block / kernel
+__device__ __forceinline__ float mom_shift(const float *__restrict__ img, int64_t nimg, float *red, int tid)
+{
+    const int64_t stride = nimg / MOM_SAMPLE > 0 ? nimg / MOM_SAMPLE : 1;
+    float v = tid < MOM_SAMPLE ? img[((int64_t)tid * stride) % nimg] : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float sft = (((red[0] + red[1]) + red[2]) + red[3]) * (1.f / MOM_SAMPLE);
+    __syncthreads();
+    return sft;
+}
 constexpr int MOM_BLOCKS = 1024;
 
 // P and S on the matrix cores: for the 16 pixels a wave takes from a tile, X^T X with X = [pixel][16 taps | 1] is ONE MFMA whose A
@@ -532,6 +550,7 @@ __global__ __launch_bounds__(256) void c1_tap_moments_kernel(const float *__rest
     v16f acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float sft = mom_shift(img, (int64_t)g.B * g.HH * g.WW, &red[0][0], tid);
     const int ngroups = (g.ntiles + MOM_GROUP - 1) / MOM_GROUP;
     float pr[MOM_GROUP][PatchRegs<NT>::N];
     auto load_group = [&](int grp) __attribute__((always_inline)) {
@@ -564,7 +583,7 @@ __global__ __launch_bounds__(256) void c1_tap_moments_kernel(const float *__rest
             if (npx == TW) {                    // full tile (the common case): masks on the packed operands only
                 float x[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = patch[buf][q][tap_off + 2 * (16 * wave + 8 * hb + i)];
+                for (int i = 0; i < 8; ++i) x[i] = patch[buf][q][tap_off + 2 * (16 * wave + 8 * hb + i)] - sft;
                 split8(x, ahi, alo);
                 const v4u mh = __builtin_bit_cast(v4u, ahi) & tap_mask, ml = __builtin_bit_cast(v4u, alo) & tap_mask;
                 ahi = __builtin_bit_cast(bf16x8, mh);
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(256) void c1_tap_moments_kernel(const float *__rest
                 for (int i = 0; i < 8; ++i) {
                     const int j = 16 * wave + 8 * hb + i;
                     const float mp = j < npx ? 1.f : 0.f;
-                    x[i] = patch[buf][q][tap_off + 2 * j] * (mt * mp);
+                    x[i] = (patch[buf][q][tap_off + 2 * j] - sft) * (mt * mp);
                     one[i] = mo * mp;
                 }
                 bf16x8 ohi, olo;
@@ -606,10 +625,14 @@ __global__ __launch_bounds__(256) void c1_tap_moments_kernel(const float *__rest
 }
 
 // mom[k] = sum over blocks (block order, double)
-__global__ __launch_bounds__(256) void c1_tap_moments_final_kernel(const float *__restrict__ partial, int nblocks, double *__restrict__ mom)
+__global__ __launch_bounds__(256) void c1_tap_moments_final_kernel(const float *__restrict__ partial, int nblocks, double *__restrict__ mom,
+                                                                   const float *__restrict__ img, int64_t nimg)
 {
     __shared__ double red[256];
+    __shared__ float reds[4];
     const int tid = threadIdx.x;
+    const float sft = mom_shift(img, nimg, reds, tid);
+    if (blockIdx.x == 0 && tid == 0) mom[MOM_N] = (double)sft;
     const int k = blockIdx.x * 32 + (tid >> 3), j = tid & 7;          // 8 lanes share a moment
     double s = 0.0;
     if (k < MOM_N) {
@@ -639,11 +662,12 @@ __global__ __launch_bounds__(64) void c1_stats_from_moments_kernel(const double 
     const double inv = 1.0 / (double)M;
     double wv[16], m[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { wv[t] = (double)w[(size_t)c * 16 + t]; m[t] = mom[mom_sum(t)] * inv; }
+    for (int t = 0; t < 16; ++t) { wv[t] = (double)w[(size_t)c * 16 + t]; m[t] = mom[mom_sum(t)] * inv; }     // m: means of the shifted taps
+    const double sft = mom[MOM_N];
     double mu = bias ? (double)bias[c] : 0.0, var = 0.0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        mu += wv[t] * m[t];
+        mu += wv[t] * (m[t] + sft);
 #pragma unroll
         for (int u = t; u < 16; ++u) {
             const double cov = mom[mom_index(t, u)] * inv - m[t] * m[u];
@@ -771,15 +795,23 @@ __global__ __launch_bounds__(256) void c1m_onepass_fixup_kernel(const double *__
     const double inv = 1.0 / (double)M;
     const double is = (double)invstd[c], mu = (double)mean[c], b = bias ? (double)bias[c] : 0.0;
     const double sc = (double)gamma[c] * is;
-    double pw = 0.0;                     // (P w_c)[t]
+    // with x = x' + shift: h = b' + sum_u w_u x'_u, b' = b + shift sum_u w_u, and sum_p x_t xhat = sum_p x'_t xhat (sum_p xhat = 0)
+    const double sft = mom[MOM_N];
+    double pw = 0.0, wsum = 0.0;         // (P' w_c)[t], sum_u w_u
 #pragma unroll
-    for (int u = 0; u < 16; ++u) pw += mom[mom_index(t, u)] * (double)w[(size_t)c * 16 + u];
-    const double St = mom[mom_sum(t)];
-    const double X = is * (pw + (b - mu) * St);               // sum_p x[p][t] xhat[p][c]
+    for (int u = 0; u < 16; ++u) {
+        const double wu = (double)w[(size_t)c * 16 + u];
+        pw += mom[mom_index(t, u)] * wu;
+        wsum += wu;
+    }
+    const double bs = b + sft * wsum;
+    const double Sp = mom[mom_sum(t)];                         // S'[t]
+    const double St = Sp + (double)M * sft;                    // S[t]
+    const double X = is * (pw + (bs - mu) * Sp);               // sum_p x[p][t] xhat[p][c]
     const double G = (double)dw[e];
     dw[e] = (float)(sc * (G - (double)dbeta[c] * inv * St - (double)dgamma[c] * inv * X));
     if (t == 0 && dbias) {               // sc (sum g - dbeta - dgamma / M sum xhat), sum xhat = invstd (sum h - M mean)
-        double sh = (double)M * b;
+        double sh = (double)M * bs;
 #pragma unroll
         for (int u = 0; u < 16; ++u) sh += (double)w[(size_t)c * 16 + u] * mom[mom_sum(u)];
         dbias[c] = (float)(-sc * (double)dgamma[c] * inv * is * (sh - (double)M * mu));
@@ -935,7 +967,7 @@ int nsg_launch_c1m_bwd_wgrad(const float *img, const float *w, const float *bias
 }
 
 // ---- the input layer by its tap moments ----
-size_t nsg_c1m_moments_bytes() { return nsg_align_up((size_t)MOM_BLOCKS * MOM_N * sizeof(float), 256) + nsg_align_up((size_t)MOM_N * sizeof(double), 256); }
+size_t nsg_c1m_moments_bytes() { return nsg_align_up((size_t)MOM_BLOCKS * MOM_N * sizeof(float), 256) + nsg_align_up((size_t)NSG_C1_MOMENTS * sizeof(double), 256); }
 
 // ws: nsg_c1m_moments_bytes() bytes; the moments (NSG_C1_MOMENTS doubles) go to mom_dst, or into ws when that is null; *mom_out = where
 int nsg_launch_c1m_moments(const float *img, int B, int LH, int LW, int HH, int WW, void *ws, double *mom_dst, const double **mom_out, hipStream_t s)
@@ -946,7 +978,8 @@ int nsg_launch_c1m_moments(const float *img, int B, int LH, int LW, int HH, int 
     int64_t blocks = (g.ntiles + MOM_GROUP - 1) / MOM_GROUP;
     if (blocks > MOM_BLOCKS) blocks = MOM_BLOCKS;
     hipLaunchKernelGGL(c1_tap_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, partial, g);
-    hipLaunchKernelGGL(c1_tap_moments_final_kernel, dim3((MOM_N + 31) / 32), dim3(256), 0, s, partial, (int)blocks, mom);
+    hipLaunchKernelGGL(c1_tap_moments_final_kernel, dim3((MOM_N + 31) / 32), dim3(256), 0, s, partial, (int)blocks, mom, img,
+                       (int64_t)B * HH * WW);
     *mom_out = mom;
     return nsg_check_launch("c1_tap_moments_kernel");
 }

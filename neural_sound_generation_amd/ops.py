@@ -477,7 +477,7 @@ def bn_backward(x, y_relu, dy, mean, invstd, gamma, dgamma=None, dbeta=None, out
 # ------------------------------------------------------------------------------------------------
 # encoder.0-2 as one operator: Conv2d(1, C, 4, 2, 1) -> BatchNorm2d -> ReLU   (src/models.py:165-167)
 # ------------------------------------------------------------------------------------------------
-C1_MOMENTS = 272      # include/nsg.h: NSG_C1_MOMENTS
+C1_MOMENTS = 273      # include/nsg.h: NSG_C1_MOMENTS
 
 
 def c1conv_bn_relu_forward(img, w, bias, gamma, beta, running_mean=None, running_var=None, training=True, eps=1e-5, momentum=0.1,

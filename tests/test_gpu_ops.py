@@ -684,6 +684,35 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
         _close(dw.cpu(), dw2.cpu(), tol=2e-5, what="dw vs unfused")
 
 
+def test_c1conv_tap_moments_with_a_large_image_mean():
+    """The bf16 input layer takes its BatchNorm statistics and weight gradient from the image's tap moments (c1_mfma.hip).  The
+    moments are taken about a shift (a sample mean of the image), so an image whose mean dwarfs its spread (mean^2 / var =
+    3600 here) costs no accuracy: against float64 CPU PyTorch."""
+    B, H, W, C = 2, 40, 128, 64
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(B, 1, H, W, generator=g) * 0.05 + 3.0
+    w = torch.randn(C, 1, 4, 4, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.2
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    h = F.conv2d(img.double(), w.double(), b.double(), 2, 1)
+    mean_ref, var_ref = h.mean(dim=(0, 2, 3)), h.var(dim=(0, 2, 3), unbiased=False)
+    mom = torch.empty(ops.C1_MOMENTS, dtype=torch.float64, device=DEV)
+    y, mean, invstd = ops.c1conv_bn_relu_forward(gpu(img.view(B, H, W)), gpu(w), gpu(b), gpu(gamma), gpu(beta), training=True,
+                                                 out_dtype=torch.bfloat16, moments=mom)
+    np.testing.assert_allclose(mean.cpu().numpy(), mean_ref.float().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(var_ref + 1e-5)).float().numpy(), rtol=2e-5)
+    # and the one-pass backward built on the same moments, against float64 autograd of the same layer
+    wd, bd, gd, bed = (t.double().requires_grad_(True) for t in (w, b, gamma, beta))
+    yd = F.relu(F.batch_norm(F.conv2d(img.double(), wd, bd, 2, 1), None, None, gd, bed, True, 0.1, 1e-5))
+    dy = torch.randn(yd.shape, generator=g).bfloat16()
+    gw, gg, gbe = torch.autograd.grad(yd, [wd, gd, bed], dy.double())
+    dw, dbias, dgm, dbt = ops.c1conv_bn_relu_backward(gpu(img.view(B, H, W)), gpu(w), gpu(b), gpu(gamma), gpu(beta), mean, invstd,
+                                                      gpu(nhwc(dy.float())).bfloat16(), moments=mom)
+    _close(dgm.cpu(), gg.float(), tol=2e-2, what="dgamma")
+    _close(dbt.cpu(), gbe.float(), tol=2e-2, what="dbeta")
+    _close(dw.cpu(), gw.float(), tol=3e-2, what="dw")       # (the bf16 image operand of the weight-gradient MFMA: 2^-9 of a mean-3 image)
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 32), (3, 40, 64, 128), (2, 10, 130, 96), (1, 3, 70, 64), (2, 5, 150, 128),
                                      (2, 5, 150, 256), (2, 40, 512, 256),    # C = 256 (BASELINE configs[3])
                                      (4, 40, 512, 128)])        # the last: BASELINE configs[1]'s decoder extent
