@@ -21,6 +21,8 @@ int nsg_launch_flat1x1_backward(const void *h, const void *dy, const float *mean
                                 const float *dbeta, const float *w, void *dh, void *dx, int64_t M, int C, void *ws, int *nblocks,
                                 const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
                                 const float *prev_beta, float **prev_partial, hipStream_t s);
+constexpr int C1_LOSS_BLOCKS = 1024;
+int nsg_launch_final_mean(const double *partial, int n, double denom, float *out, hipStream_t s);     // elementwise.hip
 bool nsg_flat1x1_fused_bwd_supported(int dtype, int C);
 size_t nsg_flat1x1_fused_bwd_workspace_bytes(int C);
 int nsg_launch_flat1x1_fused_bwd(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
@@ -98,32 +100,76 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
     }
 }
 
-// dots [B][LH][LW][16] -> out [B][HH][WW]:  out[y][x] = bias + sum of the (<= 4) taps that reach it
-__global__ void col2im_c1_kernel(const float *__restrict__ dots, const float *__restrict__ bias, float *__restrict__ out, int B,
-                                 int LH, int LW, int HH, int WW, int tanh_out)
+// dots [B][LH][LW][16] -> out [B][HH][WW]:  out[y][x] = bias + sum of the (<= 4) taps that reach it.
+// A thread owns the 2 x 2 outputs between four records: (2 ly + 1 .. 2 ly + 2) x (2 lx + 1 .. 2 lx + 2) take exactly one tap from each
+// of the records (ly, lx), (ly, lx + 1), (ly + 1, lx), (ly + 1, lx + 1), ly = -1 .. LH - 1, lx = -1 .. LW - 1 -- eight 8-byte loads for
+// four outputs, all unconditional (clamped index, validity as a factor: a load under a condition costs a branch and a full wait).
+// Taps are added in the order (ly+1,lx+1), (ly+1,lx), (ly,lx+1), (ly,lx).
+// LOSS: the reconstruction loss and its gradient in the same pass (train.py:118-129 on x_tilde = tanh(out)): per block a partial
+// of sum (pad(x_tilde) - target)^2 over the target's T >= WW columns, dpre = gscale (x_tilde - target)(1 - x_tilde^2) = the
+// gradient w.r.t. the tanh INPUT; x_tilde itself is stored only when out != null.
+template <bool LOSS>
+__global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict__ dots, const float *__restrict__ bias, float *__restrict__ out,
+                                                        int B, int LH, int LW, int HH, int WW, int tanh_out, const float *__restrict__ target,
+                                                        int T, float gscale, float *__restrict__ dpre, double *__restrict__ partial)
 {
-    const int64_t total = (int64_t)B * HH * WW;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int64_t total = (int64_t)B * (LH + 1) * (LW + 1);
     const float bv = bias ? bias[0] : 0.f;
+    double lacc = 0.0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % WW);
-        const int y = (int)((i / WW) % HH);
-        const int b = (int)(i / ((int64_t)WW * HH));
-        const int py = y & 1, px = x & 1, ry = y >> 1, rx = x >> 1;
-        float acc = bv;
+        const int lx = (int)(i % (LW + 1)) - 1;
+        const int ly = (int)((i / (LW + 1)) % (LH + 1)) - 1;
+        const int b = (int)(i / ((int64_t)(LW + 1) * (LH + 1)));
+        const float vy0 = ly >= 0 ? 1.f : 0.f, vy1 = ly + 1 < LH ? 1.f : 0.f, vx0 = lx >= 0 ? 1.f : 0.f, vx1 = lx + 1 < LW ? 1.f : 0.f;
+        const int cy0 = ly >= 0 ? ly : 0, cy1 = ly + 1 < LH ? ly + 1 : LH - 1, cx0 = lx >= 0 ? lx : 0, cx1 = lx + 1 < LW ? lx + 1 : LW - 1;
+        const float *r00 = dots + (((size_t)b * LH + cy0) * LW + cx0) * 16, *r01 = dots + (((size_t)b * LH + cy0) * LW + cx1) * 16;
+        const float *r10 = dots + (((size_t)b * LH + cy1) * LW + cx0) * 16, *r11 = dots + (((size_t)b * LH + cy1) * LW + cx1) * 16;
+        // record (ly, lx): taps [2][2..3], [3][2..3];  (ly, lx+1): [2][0..1], [3][0..1];  (ly+1, lx): [0][2..3], [1][2..3];  (ly+1, lx+1): [0][0..1], [1][0..1]
+        const f2 a2 = *reinterpret_cast<const f2 *>(r00 + 10), a3 = *reinterpret_cast<const f2 *>(r00 + 14);
+        const f2 b2 = *reinterpret_cast<const f2 *>(r01 + 8), b3 = *reinterpret_cast<const f2 *>(r01 + 12);
+        const f2 c0 = *reinterpret_cast<const f2 *>(r10 + 2), c1 = *reinterpret_cast<const f2 *>(r10 + 6);
+        const f2 d0 = *reinterpret_cast<const f2 *>(r11 + 0), d1 = *reinterpret_cast<const f2 *>(r11 + 4);
+        const float m00 = vy0 * vx0, m01 = vy0 * vx1, m10 = vy1 * vx0, m11 = vy1 * vx1;
+        float o[2][2];      // [row 2 ly + 1 + j][column 2 lx + 1 + k]
+        o[0][0] = (((bv + d0.x * m11) + c0.x * m10) + b2.x * m01) + a2.x * m00;
+        o[0][1] = (((bv + d0.y * m11) + c0.y * m10) + b2.y * m01) + a2.y * m00;
+        o[1][0] = (((bv + d1.x * m11) + c1.x * m10) + b3.x * m01) + a3.x * m00;
+        o[1][1] = (((bv + d1.y * m11) + c1.y * m10) + b3.y * m01) + a3.y * m00;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int ly = ry + py - a;
-            const int kh = (1 - py) + 2 * a;
-            if (ly < 0 || ly >= LH) continue;
+        for (int j = 0; j < 2; ++j) {
+            const int yo = 2 * ly + 1 + j;
+            if (yo < 0 || yo >= HH) continue;
 #pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) {
-                const int lx = rx + px - b2;
-                const int kw = (1 - px) + 2 * b2;
-                if (lx < 0 || lx >= LW) continue;
-                acc += dots[(((size_t)b * LH + ly) * LW + lx) * 16 + kh * 4 + kw];
+            for (int k = 0; k < 2; ++k) {
+                const int xo = 2 * lx + 1 + k;
+                if (xo < 0 || xo >= WW) continue;
+                const float v = tanh_out ? tanhf(o[j][k]) : o[j][k];
+                if (out) out[((size_t)b * HH + yo) * WW + xo] = v;
+                if (LOSS) {
+                    const float dlt = v - target[((size_t)b * HH + yo) * T + xo];
+                    lacc += (double)(dlt * dlt);
+                    dpre[((size_t)b * HH + yo) * WW + xo] = gscale * dlt * (1.f - v * v);
+                }
             }
+            if (LOSS && lx == LW - 1)          // the target's columns past the image: (0 - c)^2, no gradient
+                for (int xo = WW; xo < T; ++xo) {
+                    const float cv = target[((size_t)b * HH + yo) * T + xo];
+                    lacc += (double)(cv * cv);
+                }
         }
-        out[i] = tanh_out ? tanhf(acc) : acc;
+    }
+    if (LOSS) {       // block-level sum in double, fixed order (elementwise.hip: block_sum_store)
+        __shared__ double red[256];
+        red[threadIdx.x] = lacc;
+        __syncthreads();
+        if (threadIdx.x < 64) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int q = 0; q < 64; ++q) t += red[q];
+            partial[blockIdx.x] = t;
+        }
     }
 }
 
@@ -473,8 +519,9 @@ static int conv_forward_impl(const nsg_conv_desc *d, const void *x, const void *
     float *dots = reinterpret_cast<float *>(workspace);
     int rc = nsg_launch_gather_gemm(gg_1x1(x, w_fwd, nullptr, dots, Mp, d->C_in, 16, flags & NSG_RELU_IN, d->dtype, NSG_F32), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->OH * d->OW)), dim3(256), 0, s, dots, bias,
-                       reinterpret_cast<float *>(y), d->B, d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0);
+    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(ew_blocks((int64_t)d->B * (d->IH + 1) * (d->IW + 1))), dim3(256), 0, s, dots, bias,
+                       reinterpret_cast<float *>(y), d->B, d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0, (const float *)nullptr, 0,
+                       0.f, (float *)nullptr, (double *)nullptr);
     return nsg_check_launch("col2im_c1_kernel");
 }
 
@@ -558,8 +605,9 @@ int nsg_conv_dgrad_relu_add(const nsg_conv_desc *d, const void *dy, const void *
     float *dots = reinterpret_cast<float *>(workspace);
     int rc = nsg_launch_gather_gemm(gg_1x1(dy, w_dgrad, nullptr, dots, Mp, d->C_out, 16, 0, d->dtype, NSG_F32), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)d->B * d->IH * d->IW)), dim3(256), 0, s, dots, nullptr,
-                       reinterpret_cast<float *>(dx), d->B, d->OH, d->OW, d->IH, d->IW, 0);
+    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(ew_blocks((int64_t)d->B * (d->OH + 1) * (d->OW + 1))), dim3(256), 0, s, dots,
+                       (const float *)nullptr, reinterpret_cast<float *>(dx), d->B, d->OH, d->OW, d->IH, d->IW, 0, (const float *)nullptr, 0, 0.f,
+                       (float *)nullptr, (double *)nullptr);
     return nsg_check_launch("col2im_c1_kernel");
 }
 
@@ -617,7 +665,7 @@ int32_t nsg_bn_relu_c1convt_supported(int32_t dtype, int32_t C) { return dtype =
 size_t nsg_bn_relu_c1convt_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C)
 {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    const size_t fwd = nsg_align_up((size_t)B * H * W * 16 * sizeof(float), 256);
+    const size_t fwd = nsg_align_up((size_t)B * H * W * 16 * sizeof(float), 256) + C1_LOSS_BLOCKS * sizeof(double);    // dots | loss partials
     const size_t bwd = nsg_align_up((size_t)1024 * 2 * C * sizeof(float), 256) + nsg_c1_stencil_wgrad_workspace_bytes(C) +
                        colsum_ws_bytes((int64_t)B * 4 * H * W, 1);
     return fwd > bwd ? fwd : bwd;
@@ -640,9 +688,41 @@ int nsg_bn_relu_c1convt_forward(const void *u, int32_t dtype, const float *mean,
     float *dots = reinterpret_cast<float *>(workspace);
     int rc = nsg_launch_bnrelu_dots(u, mean, invstd, gamma, beta, w, dots, (int64_t)B * H * W, C, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel, dim3(ew_blocks((int64_t)B * 4 * H * W)), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H, 2 * W,
-                       (flags & NSG_TANH_OUT) ? 1 : 0);
+    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(ew_blocks((int64_t)B * (H + 1) * (W + 1))), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H,
+                       2 * W, (flags & NSG_TANH_OUT) ? 1 : 0, (const float *)nullptr, 0, 0.f, (float *)nullptr, (double *)nullptr);
     return nsg_check_launch("col2im_c1_kernel");
+}
+
+/* nsg_bn_relu_c1convt_forward (with Tanh) + the reconstruction loss of train.py:118-129 in the same pass: loss_out[0] =
+ * mean((pad(x_tilde) - target)^2) over the target's [B][2H][T] elements (T >= 2W: x_tilde zero-padded on the right),
+ * dpre [B][2H][2W] = grad_scale * 2 / (B 2H T) * (x_tilde - target) * (1 - x_tilde^2): the gradient w.r.t. the Tanh's INPUT
+ * (feed it to nsg_bn_relu_c1convt_backward); y = x_tilde is stored only when not NULL. */
+int nsg_bn_relu_c1convt_forward_mse(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                    const float *w, const float *bias, float *y, const float *target, int32_t T, float grad_scale,
+                                    float *loss_out, float *dpre, int32_t B, int32_t H, int32_t W, int32_t C, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    NSG_REQUIRE(u && mean && invstd && gamma && beta && w && target && loss_out && dpre, NSG_E_INVALID, "nsg_bn_relu_c1convt_forward_mse: null pointer");
+    NSG_REQUIRE(B > 0 && H > 0 && W > 0 && T >= 2 * W, NSG_E_INVALID, "nsg_bn_relu_c1convt_forward_mse: bad extent (T >= 2W)");
+    NSG_REQUIRE(nsg_bn_relu_c1convt_supported(dtype, C), NSG_E_UNSUPPORTED,
+                "nsg_bn_relu_c1convt_forward_mse: needs bf16 tensors and C = 32, 64, 96, 128 or 256 (use the separate operators otherwise)");
+    NSG_REQUIRE(nsg_aligned16(u) && nsg_aligned16(w), NSG_E_INVALID, "nsg_bn_relu_c1convt_forward_mse: u and w must be 16-byte aligned");
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_bn_relu_c1convt_workspace_bytes(B, H, W, C), NSG_E_WORKSPACE,
+                "nsg_bn_relu_c1convt_forward_mse: workspace too small");
+    NSG_REQUIRE((int64_t)B * H * W * C <= 0x7fffffffLL * 4, NSG_E_UNSUPPORTED, "nsg_bn_relu_c1convt_forward_mse: tensor too large");
+    hipStream_t s = (hipStream_t)stream;
+    float *dots = reinterpret_cast<float *>(workspace);
+    double *partial = reinterpret_cast<double *>(reinterpret_cast<char *>(workspace) + nsg_align_up((size_t)B * H * W * 16 * sizeof(float), 256));
+    int rc = nsg_launch_bnrelu_dots(u, mean, invstd, gamma, beta, w, dots, (int64_t)B * H * W, C, s);
+    if (rc) return rc;
+    const int64_t n = (int64_t)B * 2 * H * T;
+    int nb = ew_blocks((int64_t)B * (H + 1) * (W + 1));
+    if (nb > C1_LOSS_BLOCKS) nb = C1_LOSS_BLOCKS;
+    hipLaunchKernelGGL(col2im_c1_kernel<true>, dim3(nb), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H, 2 * W, 1, target, T,
+                       grad_scale * 2.0f / (float)n, dpre, partial);
+    rc = nsg_check_launch("col2im_c1_kernel<loss>");
+    if (rc) return rc;
+    return nsg_launch_final_mean(partial, nb, (double)n, loss_out, s);
 }
 
 int nsg_bn_relu_c1convt_backward(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma, const float *beta,

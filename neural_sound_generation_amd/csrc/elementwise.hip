@@ -343,6 +343,13 @@ constexpr int RED_BLOCKS = 1024;
 
 }  // namespace
 
+// out[0] = (sum of n block partials) / denom: the closing kernel of every loss (also conv_api.hip's fused output layer + loss)
+int nsg_launch_final_mean(const double *partial, int n, double denom, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, s, partial, n, denom, out);
+    return nsg_check_launch("final_mean_kernel");
+}
+
 extern "C" {
 
 int nsg_relu_backward_add(const void *a, const void *b, const void *x, void *dx, int64_t n, int32_t dtype, void *stream)

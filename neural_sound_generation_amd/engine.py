@@ -119,6 +119,7 @@ def _bump(bn: "BNParams"):
 # round 2 (same box, alternating runs): 8.815 ms off, 8.715 with the transposed conv only (=2), 8.670 with all five (=1), the
 # in-region conv rate 920 / 906 / 879 TF.  Off by default: the step gains 1.7 % at most, the kernel whose roofline the
 # bench reports loses 4.5 % (NSG_PATCH_BN_STATS=1 or 2 turns it on).
+FUSED_OUT_LOSS = _os.environ.get("NSG_FUSED_OUT_LOSS", "1") == "1"  # reconstruction loss + Tanh backward in the output layer's image pass
 FUSED_1X1_BWD = _os.environ.get("NSG_FUSED_1X1_BWD", "1") == "1"    # the 1x1 conv's data and weight gradients in one kernel (C = 128)
 PATCH_BN_STATS = int(_os.environ.get("NSG_PATCH_BN_STATS", "0"))      # 1: every patch_gemm layer in front of a BatchNorm; 2: the transposed conv only
 
@@ -278,9 +279,12 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
 # ------------------------------------------------------------------------------------------------
 # Decoder   (src/models.py:175-184)
 # ------------------------------------------------------------------------------------------------
-def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None, zq_is_relu=False):
+def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None, zq_is_relu=False, mse_target=None):
     """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype.
-    zq_is_relu: zq already holds max(0, z_q) in `dtype` (the quantiser wrote it: ops.vq_forward codes_bf16="relu")."""
+    zq_is_relu: zq already holds max(0, z_q) in `dtype` (the quantiser wrote it: ops.vq_forward codes_bf16="relu").
+    mse_target: the training step's reconstruction target (B, 4h, T, 1) fp32.  Where the fused output layer runs, the loss and
+    the gradient w.r.t. the Tanh's input come out of the pass that forms the image: returns ((loss, dpre), saved) instead of
+    (x_tilde, saved) -- test with isinstance(result, tuple); decoder_backward then takes dpre with dxt_is_pre_tanh=True."""
     B, H, W, D = zq.shape
     if not (zq_is_relu and zq.dtype == dtype):
         zq = ops.convert(zq, dtype, relu=True)                   # decoder.0's leading ReLU, applied once here
@@ -293,6 +297,9 @@ def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, p
     d6 = ops.conv_desc(B, dT.OH, dT.OW, D, 1, 4, 2, 1, transposed=True, dtype=dtype)
     if FUSED_OUT_LAYER and ops.bn_relu_c1convt_supported(u.dtype, D):
         a, wd6 = None, None                          # relu(bn(u)) is never materialised; the backward rebuilds it from u
+        if mse_target is not None and FUSED_OUT_LOSS:
+            loss, dpre, _ = ops.bn_relu_c1convt_forward_mse(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias, mse_target)
+            return (loss, dpre), (r1, u, a, m, i, None, dT, d6, wdT, wd6, s0, s1)
         xt = ops.bn_relu_c1convt_forward(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias, tanh=True)
     else:
         a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)

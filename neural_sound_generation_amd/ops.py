@@ -689,6 +689,28 @@ def bn_relu_c1convt_forward(u, mean, invstd, gamma, beta, w, bias, tanh=True):
     return y
 
 
+def bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target, grad_scale=1.0, want_image=False):
+    """bn_relu_c1convt_forward(tanh=True) + mse_padded + tanh_backward in one pass over the tap products: target fp32
+    (B, 2H, T[, 1]) with T >= 2W.  Returns (loss (1,), dpre (B, 2H, 2W, 1) = the gradient w.r.t. the Tanh's input, x_tilde or None)."""
+    _chk(u, "u", None); _chk(w, "w", torch.float32); _chk(target, "target", torch.float32)
+    B, H, W, C = u.shape
+    T = target.numel() // (B * 2 * H)
+    if target.numel() != B * 2 * H * T or T < 2 * W:
+        raise ValueError("bn_relu_c1convt_forward_mse: target must be (B, 2H, T) with T >= 2W")
+    dev = u.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dpre = torch.empty((B, 2 * H, 2 * W, 1), dtype=torch.float32, device=dev)
+    y = torch.empty((B, 2 * H, 2 * W, 1), dtype=torch.float32, device=dev) if want_image else None
+    nb = _lib.query("nsg_bn_relu_c1convt_workspace_bytes", c_int32(B), c_int32(H), c_int32(W), c_int32(C))
+    ws = WS.get(nb, dev)
+    _lib.tag("bn_relu_c1convt_forward_mse (fused output layer + loss)", 2.0 * 16 * u.numel(),
+             u.numel() * _es(u) + 4.0 * (2 * dpre.numel() + (dpre.numel() if want_image else 0)))
+    _lib.call("nsg_bn_relu_c1convt_forward_mse", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias),
+              _p(y), _p(target), c_int32(T), c_float(grad_scale), _p(loss), _p(dpre), c_int32(B), c_int32(H), c_int32(W), c_int32(C),
+              _p(ws), c_size_t(nb), _stream())
+    return loss, dpre, y
+
+
 def bn_relu_c1convt_backward(u, mean, invstd, gamma, beta, w, dy, dw=None, dbias=None, dgamma=None, dbeta=None, du_colsum=None):
     """dy: fp32 gradient image (B, 2H, 2W[, 1]) w.r.t. the transposed conv's output (before the tanh).
     Returns (du like u, dw (C, 1, 4, 4), dbias (1,), dgamma, dbeta); du_colsum: optional [C] tensor receiving the column

@@ -98,10 +98,14 @@ class FusedTrainStep:
         if self.spk is not None and g is not None:
             g = g.view(-1).to(torch.int64).contiguous()
             zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g), out_dtype=self.dtype)
-        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs, zq_is_relu=lean)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
-        loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
-        dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)
+        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs, zq_is_relu=lean, mse_target=x)
+        if isinstance(xt, tuple):       # the fused output layer formed the loss and the gradient at the Tanh's input with the image
+            loss_recons, dpre = xt
+            dzq, _ = engine.decoder_backward(dpre, ds, self.decP, need_dz=True, dxt_is_pre_tanh=True, gout=self.g_dec)
+        else:
+            loss_recons, dxt = ops.mse_padded(xt, x, B * H, xt.shape[2], T)
+            dzq, _ = engine.decoder_backward(dxt, ds, self.decP, need_dz=True, gout=self.g_dec)
         if self.spk is not None:
             if g is not None:   # d loss / d speaker rows = per-clip pixel sums of dzq, scattered to the speakers
                 gs = ops.index_add_rows(g, ops.clip_colsum(dzq, B), self.spk.weight.shape[0])

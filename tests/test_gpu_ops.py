@@ -684,6 +684,33 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
         _close(dw.cpu(), dw2.cpu(), tol=2e-5, what="dw vs unfused")
 
 
+@pytest.mark.parametrize("B,H,W,C,T", [(2, 5, 150, 64, 300), (3, 40, 64, 128, 131), (1, 3, 70, 32, 143)])
+def test_fused_output_layer_with_reconstruction_loss(B, H, W, C, T):
+    """nsg_bn_relu_c1convt_forward_mse = the fused output layer (with Tanh) + nsg_mse_padded + nsg_tanh_backward in one pass over
+    the tap products: the same image bit for bit, the loss to the order of its double sums, the gradient at the Tanh's input to
+    one rounding; with a target wider than the image (the reference zero-pads x_tilde on the host, train.py:118-127)."""
+    g = torch.Generator().manual_seed(B + W + C)
+    u = gpu(torch.randn(B, H, W, C, generator=g) * 1.2 + 0.3).bfloat16()
+    w = gpu(torch.randn(C, 1, 4, 4, generator=g) * 0.2)
+    bias = gpu(torch.randn(1, generator=g) * 0.1)
+    gamma, beta = gpu(torch.rand(C, generator=g) + 0.5), gpu(torch.randn(C, generator=g) * 0.3)
+    mean, invstd = ops.bn_stats(u, C, None, None)
+    target = gpu(torch.rand(B, 2 * H, T, 1, generator=g))
+    xt = ops.bn_relu_c1convt_forward(u, mean, invstd, gamma, beta, w, bias, tanh=True)
+    loss_ref, dxt = ops.mse_padded(xt, target, B * 2 * H, 2 * W, T)
+    dpre_ref = ops.tanh_backward(dxt, xt)
+    loss, dpre, img = ops.bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target, want_image=True)
+    assert torch.equal(img, xt)
+    np.testing.assert_allclose(loss.cpu().numpy(), loss_ref.cpu().numpy(), rtol=1e-6)
+    _close(dpre.cpu(), dpre_ref.cpu(), tol=1e-6, what="gradient at the Tanh's input")
+    loss2, dpre2, none = ops.bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target)
+    assert none is None and torch.equal(loss2, loss) and torch.equal(dpre2, dpre)
+    # float64 CPU statement of the loss on the stored image
+    pad = torch.zeros(B, 2 * H, T, dtype=torch.float64)
+    pad[:, :, :2 * W] = xt.cpu().double().view(B, 2 * H, 2 * W)
+    np.testing.assert_allclose(float(loss.cpu()), float(((pad - target.cpu().double().view(B, 2 * H, T)) ** 2).mean()), rtol=1e-6)
+
+
 def test_c1conv_tap_moments_with_a_large_image_mean():
     """The bf16 input layer takes its BatchNorm statistics and weight gradient from the image's tap moments (c1_mfma.hip).  The
     moments are taken about a shift (a sample mean of the image), so an image whose mean dwarfs its spread (mean^2 / var =
