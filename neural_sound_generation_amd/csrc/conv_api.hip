@@ -130,6 +130,17 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
         const f2 b2 = *reinterpret_cast<const f2 *>(r01 + 8), b3 = *reinterpret_cast<const f2 *>(r01 + 12);
         const f2 c0 = *reinterpret_cast<const f2 *>(r10 + 2), c1 = *reinterpret_cast<const f2 *>(r10 + 6);
         const f2 d0 = *reinterpret_cast<const f2 *>(r11 + 0), d1 = *reinterpret_cast<const f2 *>(r11 + 4);
+        float tv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (LOSS) {         // the four target values, unconditional (clamped) like the records
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int yo = 2 * ly + 1 + j, xo = 2 * lx + 1 + k;
+                    const int yc = yo < 0 ? 0 : (yo >= HH ? HH - 1 : yo), xc = xo < 0 ? 0 : (xo >= WW ? WW - 1 : xo);
+                    tv[j][k] = target[((size_t)b * HH + yc) * T + xc];
+                }
+        }
         const float m00 = vy0 * vx0, m01 = vy0 * vx1, m10 = vy1 * vx0, m11 = vy1 * vx1;
         float o[2][2];      // [row 2 ly + 1 + j][column 2 lx + 1 + k]
         o[0][0] = (((bv + d0.x * m11) + c0.x * m10) + b2.x * m01) + a2.x * m00;
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
                 const float v = tanh_out ? tanhf(o[j][k]) : o[j][k];
                 if (out) out[((size_t)b * HH + yo) * WW + xo] = v;
                 if (LOSS) {
-                    const float dlt = v - target[((size_t)b * HH + yo) * T + xo];
+                    const float dlt = v - tv[j][k];
                     lacc += (double)(dlt * dlt);
                     dpre[((size_t)b * HH + yo) * WW + xo] = gscale * dlt * (1.f - v * v);
                 }
