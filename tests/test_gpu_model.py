@@ -552,7 +552,8 @@ def test_module_surface_on_gpu():
         m.cpu()(c.cpu())
 
 
-@pytest.mark.parametrize("dim,z_dim,B,T", [(64, 128, 2, 256), (128, 512, 2, 1024), (256, 8192, 1, 1024)])
+@pytest.mark.parametrize("dim,z_dim,B,T", [(64, 128, 2, 256), (128, 512, 2, 1024), (256, 8192, 1, 1024),
+                                           (128, 512, 3, 131)])     # T = 131: x_tilde is 128 wide, the target 3 columns wider (train.py:118-127)
 def test_bf16_mode_against_fp32_oracle(dim, z_dim, B, T):
     """compute_dtype=bfloat16: bf16 activations / conv operands, fp32 accumulation, BatchNorm statistics,
     quantiser, parameters and optimiser.  It cannot meet the fp32 parity bar (8 mantissa bits); what is
