@@ -317,11 +317,12 @@ NSG_API int nsg_bn_relu_c1convt_forward(const void *u, int32_t dtype, const floa
  * target [B][2H][T] fp32 with T >= 2W (x_tilde is zero-padded on the right to the target's width, as the reference pads it on the
  * host); loss_out[0] = mean((pad(x_tilde) - target)^2); dpre [B][2H][2W] = grad_scale * 2 / (B 2H T) * (x_tilde - target) *
  * (1 - x_tilde^2) = the gradient w.r.t. the Tanh's INPUT (what nsg_bn_relu_c1convt_backward takes as dy); y = x_tilde is stored
- * only when not NULL.  Replaces nsg_bn_relu_c1convt_forward + nsg_mse_padded + nsg_tanh_backward in a training step. */
+ * only when not NULL; dbias [1] or NULL = sum of dpre, the transposed conv's bias gradient (pass dbias = NULL to the backward
+ * then).  Replaces nsg_bn_relu_c1convt_forward + nsg_mse_padded + nsg_tanh_backward in a training step. */
 NSG_API int nsg_bn_relu_c1convt_forward_mse(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma,
                                             const float *beta, const float *w, const float *bias, float *y, const float *target,
-                                            int32_t T, float grad_scale, float *loss_out, float *dpre, int32_t B, int32_t H,
-                                            int32_t W, int32_t C, void *workspace, size_t workspace_bytes, void *stream);
+                                            int32_t T, float grad_scale, float *loss_out, float *dpre, float *dbias, int32_t B,
+                                            int32_t H, int32_t W, int32_t C, void *workspace, size_t workspace_bytes, void *stream);
 /* dy: gradient w.r.t. the transposed conv's output (BEFORE the tanh: nsg_tanh_backward).  Outputs: du (dtype, the
  * gradient w.r.t. u), du_colsum [C] or NULL (column sums of du = the bias gradient of the conv that wrote u, as
  * nsg_bn_backward's dx_colsum), dw [C][16], dbias [1] or NULL, dgamma [C], dbeta [C], all overwritten. */

@@ -74,7 +74,7 @@ _SIGS = {
     "nsg_bn_relu_c1convt_supported": (c_int32, [c_int32, c_int32]),
     "nsg_bn_relu_c1convt_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "nsg_bn_relu_c1convt_forward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
-    "nsg_bn_relu_c1convt_forward_mse": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, c_int32, c_int32, c_int32,
+    "nsg_bn_relu_c1convt_forward_mse": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, c_int32, c_int32, c_int32,
                                                c_int32, _P, c_size_t, _P]),
     "nsg_bn_relu_c1convt_backward": (None, [_P, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P,
                                             c_size_t, _P]),

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
     typedef float f2 __attribute__((ext_vector_type(2)));
     const int64_t total = (int64_t)B * (LH + 1) * (LW + 1);
     const float bv = bias ? bias[0] : 0.f;
-    double lacc = 0.0;
+    double lacc = 0.0, gacc = 0.0;      // loss partial; sum of dpre (= the transposed conv's bias gradient)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int lx = (int)(i % (LW + 1)) - 1;
         const int ly = (int)((i / (LW + 1)) % (LH + 1)) - 1;
@@ -160,7 +160,9 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
                 if (LOSS) {
                     const float dlt = v - tv[j][k];
                     lacc += (double)(dlt * dlt);
-                    dpre[((size_t)b * HH + yo) * WW + xo] = gscale * dlt * (1.f - v * v);
+                    const float gp = gscale * dlt * (1.f - v * v);
+                    dpre[((size_t)b * HH + yo) * WW + xo] = gp;
+                    gacc += (double)gp;
                 }
             }
             if (LOSS && lx == LW - 1)          // the target's columns past the image: (0 - c)^2, no gradient
@@ -180,6 +182,16 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
             double t = 0.0;
             for (int q = 0; q < 64; ++q) t += red[q];
             partial[blockIdx.x] = t;
+        }
+        __syncthreads();
+        red[threadIdx.x] = gacc;
+        __syncthreads();
+        if (threadIdx.x < 64) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int q = 0; q < 64; ++q) t += red[q];
+            partial[gridDim.x + blockIdx.x] = t;
         }
     }
 }
@@ -676,7 +688,7 @@ int32_t nsg_bn_relu_c1convt_supported(int32_t dtype, int32_t C) { return dtype =
 size_t nsg_bn_relu_c1convt_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C)
 {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    const size_t fwd = nsg_align_up((size_t)B * H * W * 16 * sizeof(float), 256) + C1_LOSS_BLOCKS * sizeof(double);    // dots | loss partials
+    const size_t fwd = nsg_align_up((size_t)B * H * W * 16 * sizeof(float), 256) + 2 * C1_LOSS_BLOCKS * sizeof(double);    // dots | loss, bias-gradient partials
     const size_t bwd = nsg_align_up((size_t)1024 * 2 * C * sizeof(float), 256) + nsg_c1_stencil_wgrad_workspace_bytes(C) +
                        colsum_ws_bytes((int64_t)B * 4 * H * W, 1);
     return fwd > bwd ? fwd : bwd;
@@ -707,10 +719,11 @@ int nsg_bn_relu_c1convt_forward(const void *u, int32_t dtype, const float *mean,
 /* nsg_bn_relu_c1convt_forward (with Tanh) + the reconstruction loss of train.py:118-129 in the same pass: loss_out[0] =
  * mean((pad(x_tilde) - target)^2) over the target's [B][2H][T] elements (T >= 2W: x_tilde zero-padded on the right),
  * dpre [B][2H][2W] = grad_scale * 2 / (B 2H T) * (x_tilde - target) * (1 - x_tilde^2): the gradient w.r.t. the Tanh's INPUT
- * (feed it to nsg_bn_relu_c1convt_backward); y = x_tilde is stored only when not NULL. */
+ * (feed it to nsg_bn_relu_c1convt_backward); y = x_tilde is stored only when not NULL; dbias [1] or NULL = sum of dpre = the
+ * transposed conv's bias gradient (then pass dbias = NULL to the backward: it would re-read dpre for it). */
 int nsg_bn_relu_c1convt_forward_mse(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma, const float *beta,
                                     const float *w, const float *bias, float *y, const float *target, int32_t T, float grad_scale,
-                                    float *loss_out, float *dpre, int32_t B, int32_t H, int32_t W, int32_t C, void *workspace,
+                                    float *loss_out, float *dpre, float *dbias, int32_t B, int32_t H, int32_t W, int32_t C, void *workspace,
                                     size_t workspace_bytes, void *stream)
 {
     NSG_REQUIRE(u && mean && invstd && gamma && beta && w && target && loss_out && dpre, NSG_E_INVALID, "nsg_bn_relu_c1convt_forward_mse: null pointer");
@@ -733,7 +746,9 @@ int nsg_bn_relu_c1convt_forward_mse(const void *u, int32_t dtype, const float *m
                        grad_scale * 2.0f / (float)n, dpre, partial);
     rc = nsg_check_launch("col2im_c1_kernel<loss>");
     if (rc) return rc;
-    return nsg_launch_final_mean(partial, nb, (double)n, loss_out, s);
+    rc = nsg_launch_final_mean(partial, nb, (double)n, loss_out, s);
+    if (rc || !dbias) return rc;
+    return nsg_launch_final_mean(partial + nb, nb, 1.0, dbias, s);      // sum of dpre: the transposed conv's bias gradient
 }
 
 int nsg_bn_relu_c1convt_backward(const void *u, int32_t dtype, const float *mean, const float *invstd, const float *gamma, const float *beta,

@@ -279,12 +279,15 @@ def encoder_backward(dze, saved, P: EncoderParams, gout=None):
 # ------------------------------------------------------------------------------------------------
 # Decoder   (src/models.py:175-184)
 # ------------------------------------------------------------------------------------------------
-def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None, zq_is_relu=False, mse_target=None):
+def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, packs=None, zq_is_relu=False, mse_target=None,
+                    mse_dbias=None):
     """zq NHWC (B, h, w, D) -> x_tilde fp32 NHWC (B, 4h, 4w, 1); activations in between stored as dtype.
     zq_is_relu: zq already holds max(0, z_q) in `dtype` (the quantiser wrote it: ops.vq_forward codes_bf16="relu").
     mse_target: the training step's reconstruction target (B, 4h, T, 1) fp32.  Where the fused output layer runs, the loss and
     the gradient w.r.t. the Tanh's input come out of the pass that forms the image: returns ((loss, dpre), saved) instead of
-    (x_tilde, saved) -- test with isinstance(result, tuple); decoder_backward then takes dpre with dxt_is_pre_tanh=True."""
+    (x_tilde, saved) -- test with isinstance(result, tuple); decoder_backward then takes dpre with dxt_is_pre_tanh=True.
+    mse_dbias: optional (1,) tensor for the output conv's bias gradient (= sum of dpre), formed in the same pass; the backward
+    then leaves it alone."""
     B, H, W, D = zq.shape
     if not (zq_is_relu and zq.dtype == dtype):
         zq = ops.convert(zq, dtype, relu=True)                   # decoder.0's leading ReLU, applied once here
@@ -298,8 +301,9 @@ def decoder_forward(zq, P: DecoderParams, training: bool, dtype=torch.float32, p
     if FUSED_OUT_LAYER and ops.bn_relu_c1convt_supported(u.dtype, D):
         a, wd6 = None, None                          # relu(bn(u)) is never materialised; the backward rebuilds it from u
         if mse_target is not None and FUSED_OUT_LOSS:
-            loss, dpre, _ = ops.bn_relu_c1convt_forward_mse(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias, mse_target)
-            return (loss, dpre), (r1, u, a, m, i, None, dT, d6, wdT, wd6, s0, s1)
+            loss, dpre, _ = ops.bn_relu_c1convt_forward_mse(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias, mse_target,
+                                                            dbias=mse_dbias)
+            return (loss, dpre), (r1, u, a, m, i, ("bias gradient done", mse_dbias) if mse_dbias is not None else None, dT, d6, wdT, wd6, s0, s1)
         xt = ops.bn_relu_c1convt_forward(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, P.convt6.bias, tanh=True)
     else:
         a = ops.bn_apply(u, m, i, P.bn4.weight, P.bn4.bias, relu=True)
@@ -317,8 +321,10 @@ def decoder_backward(dxt, saved, P: DecoderParams, need_dz: bool = True, dxt_is_
     dpre = dxt if dxt_is_pre_tanh else ops.tanh_backward(dxt, xt)
     dbT = o[17] if o[17] is not None else torch.empty(u.shape[-1], dtype=torch.float32, device=u.device)
     if a is None:       # fused output layer: BatchNorm backward, the transposed conv's data and weight gradients in two passes over u
+        db_done = xt[1] if isinstance(xt, tuple) else None       # the forward's loss pass already summed dpre (decoder_forward: mse_dbias)
         du, dw6, db6, dg4, dbe4 = ops.bn_relu_c1convt_backward(u, m, i, P.bn4.weight, P.bn4.bias, P.convt6.weight, dpre, dw=o[20],
-                                                               dbias=o[21], dgamma=o[18], dbeta=o[19], du_colsum=dbT)
+                                                               dbias=db_done if db_done is not None else o[21], dgamma=o[18], dbeta=o[19],
+                                                               du_colsum=dbT, want_dbias=db_done is None)
     else:
         dw6, db6 = ops.conv_wgrad(d6, a, dpre, P.convt6.weight.shape, dw=o[20], dbias=o[21])
         da = ops.conv_dgrad(d6, dpre, wd6)

@@ -689,9 +689,10 @@ def bn_relu_c1convt_forward(u, mean, invstd, gamma, beta, w, bias, tanh=True):
     return y
 
 
-def bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target, grad_scale=1.0, want_image=False):
+def bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target, grad_scale=1.0, want_image=False, dbias=None):
     """bn_relu_c1convt_forward(tanh=True) + mse_padded + tanh_backward in one pass over the tap products: target fp32
-    (B, 2H, T[, 1]) with T >= 2W.  Returns (loss (1,), dpre (B, 2H, 2W, 1) = the gradient w.r.t. the Tanh's input, x_tilde or None)."""
+    (B, 2H, T[, 1]) with T >= 2W.  Returns (loss (1,), dpre (B, 2H, 2W, 1) = the gradient w.r.t. the Tanh's input, x_tilde or None).
+    dbias: optional (1,) tensor receiving sum(dpre), the transposed conv's bias gradient."""
     _chk(u, "u", None); _chk(w, "w", torch.float32); _chk(target, "target", torch.float32)
     B, H, W, C = u.shape
     T = target.numel() // (B * 2 * H)
@@ -706,15 +707,17 @@ def bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target, g
     _lib.tag("bn_relu_c1convt_forward_mse (fused output layer + loss)", 2.0 * 16 * u.numel(),
              u.numel() * _es(u) + 4.0 * (2 * dpre.numel() + (dpre.numel() if want_image else 0)))
     _lib.call("nsg_bn_relu_c1convt_forward_mse", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(bias),
-              _p(y), _p(target), c_int32(T), c_float(grad_scale), _p(loss), _p(dpre), c_int32(B), c_int32(H), c_int32(W), c_int32(C),
+              _p(y), _p(target), c_int32(T), c_float(grad_scale), _p(loss), _p(dpre), _p(dbias), c_int32(B), c_int32(H), c_int32(W), c_int32(C),
               _p(ws), c_size_t(nb), _stream())
     return loss, dpre, y
 
 
-def bn_relu_c1convt_backward(u, mean, invstd, gamma, beta, w, dy, dw=None, dbias=None, dgamma=None, dbeta=None, du_colsum=None):
+def bn_relu_c1convt_backward(u, mean, invstd, gamma, beta, w, dy, dw=None, dbias=None, dgamma=None, dbeta=None, du_colsum=None,
+                             want_dbias=True):
     """dy: fp32 gradient image (B, 2H, 2W[, 1]) w.r.t. the transposed conv's output (before the tanh).
     Returns (du like u, dw (C, 1, 4, 4), dbias (1,), dgamma, dbeta); du_colsum: optional [C] tensor receiving the column
-    sums of du (the bias gradient of the conv in front of the BatchNorm)."""
+    sums of du (the bias gradient of the conv in front of the BatchNorm).  want_dbias=False: the bias gradient (sum of dy) is
+    not formed (bn_relu_c1convt_forward_mse already gave it); dbias is returned as passed."""
     _chk(u, "u", None); _chk(w, "w", torch.float32); _chk(dy, "dy", torch.float32)
     B, H, W, C = u.shape
     if dy.numel() != B * 4 * H * W:
@@ -722,14 +725,15 @@ def bn_relu_c1convt_backward(u, mean, invstd, gamma, beta, w, dy, dw=None, dbias
     dev = u.device
     du = torch.empty_like(u)
     dw = dw if dw is not None else torch.empty_like(w)
-    dbias = dbias if dbias is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    if want_dbias:
+        dbias = dbias if dbias is not None else torch.empty(1, dtype=torch.float32, device=dev)
     dgamma = dgamma if dgamma is not None else torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = dbeta if dbeta is not None else torch.empty(C, dtype=torch.float32, device=dev)
     nb = _lib.query("nsg_bn_relu_c1convt_workspace_bytes", c_int32(B), c_int32(H), c_int32(W), c_int32(C))
     ws = WS.get(nb, dev)
     _lib.tag("bn_relu_c1convt_backward (fused output layer)", 2.0 * 16 * u.numel() * 3, 3.0 * u.numel() * _es(u) + 2.0 * 4.0 * dy.numel())
     _lib.call("nsg_bn_relu_c1convt_backward", _p(u), c_int32(nsg_dtype(u.dtype)), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w), _p(dy),
-              _p(du), _p(du_colsum), _p(dw), _p(dbias), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws),
+              _p(du), _p(du_colsum), _p(dw), _p(dbias if want_dbias else None), _p(dgamma), _p(dbeta), c_int32(B), c_int32(H), c_int32(W), c_int32(C), _p(ws),
               c_size_t(nb), _stream())
     return du, dw, dbias, dgamma, dbeta
 

@@ -99,7 +99,8 @@ class FusedTrainStep:
             g = g.view(-1).to(torch.int64).contiguous()
             zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g), out_dtype=self.dtype)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
-        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs, zq_is_relu=lean, mse_target=x)
+        xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs, zq_is_relu=lean, mse_target=x,
+                                        mse_dbias=self.g_dec[21])
         if isinstance(xt, tuple):       # the fused output layer formed the loss and the gradient at the Tanh's input with the image
             loss_recons, dpre = xt
             dzq, _ = engine.decoder_backward(dpre, ds, self.decP, need_dz=True, dxt_is_pre_tanh=True, gout=self.g_dec)

@@ -703,8 +703,10 @@ def test_fused_output_layer_with_reconstruction_loss(B, H, W, C, T):
     assert torch.equal(img, xt)
     np.testing.assert_allclose(loss.cpu().numpy(), loss_ref.cpu().numpy(), rtol=1e-6)
     _close(dpre.cpu(), dpre_ref.cpu(), tol=1e-6, what="gradient at the Tanh's input")
-    loss2, dpre2, none = ops.bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target)
+    db = torch.empty(1, device=DEV)
+    loss2, dpre2, none = ops.bn_relu_c1convt_forward_mse(u, mean, invstd, gamma, beta, w, bias, target, dbias=db)
     assert none is None and torch.equal(loss2, loss) and torch.equal(dpre2, dpre)
+    np.testing.assert_allclose(float(db.cpu()), float(dpre.double().sum().cpu()), rtol=1e-5, atol=1e-9)     # the transposed conv's bias gradient
     # float64 CPU statement of the loss on the stored image
     pad = torch.zeros(B, 2 * H, T, dtype=torch.float64)
     pad[:, :, :2 * W] = xt.cpu().double().view(B, 2 * H, 2 * W)
