@@ -460,10 +460,70 @@ inline int check_mc(const char *fn, int64_t M, int C, int dtype)
 
 }  // namespace
 
+// The same in ONE launch for up to MAX_SLABS records (the flat 1x1 GEMM writes 256-512): one block per 4 channels, thread j takes
+// records j, j + 256, ... (all loads first), three fixed-shape tree sums in double: N, S, T = sum (Q_t + S_t^2 / n_t).
+__global__ __launch_bounds__(256) void bn_stats_tiles_onepass_kernel(const float *__restrict__ tiles, int ntiles, int64_t M, int C, float eps,
+                                                                     float momentum, float *mean, float *invstd, float *running_mean,
+                                                                     float *running_var)
+{
+    constexpr int PER = MAX_SLABS / 256;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * 4;
+    v4f nv[PER], sv[PER], qv[PER];
+    float rm0[4], rv0[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        rm0[e] = running_mean ? running_mean[c0 + e] : 0.f;
+        rv0[e] = running_var ? running_var[c0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int t = tid + 256 * i;
+        const int tc = t < ntiles ? t : ntiles - 1;                  // clamped, unconditional loads; masked below
+        const float *rec = tiles + (size_t)tc * 3 * C + c0;
+        nv[i] = *reinterpret_cast<const v4f *>(rec);
+        sv[i] = *reinterpret_cast<const v4f *>(rec + C);
+        qv[i] = *reinterpret_cast<const v4f *>(rec + 2 * C);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double n = 0.0, sm = 0.0, tq = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const bool live = tid + 256 * i < ntiles;
+            const double ni = live ? (double)nv[i][e] : 0.0, si = live ? (double)sv[i][e] : 0.0, qi = live ? (double)qv[i][e] : 0.0;
+            n += ni;
+            sm += si;
+            tq += ni > 0.0 ? qi + si * si / ni : 0.0;
+        }
+        const double N = block_sum256(n, red, tid), S = block_sum256(sm, red, tid), T = block_sum256(tq, red, tid);
+        if (tid == 0) {
+            const int c = c0 + e;
+            const double mu = S / N;
+            double m2 = T - S * S / N;
+            if (m2 < 0.0) m2 = 0.0;
+            const double var_b = m2 / (double)M;
+            mean[c] = (float)mu;
+            invstd[c] = (float)(1.0 / sqrt(var_b + (double)eps));
+            if (running_mean) running_mean[c] = (1.f - momentum) * rm0[e] + momentum * (float)mu;
+            if (running_var) {
+                const double var_u = M > 1 ? m2 / (double)(M - 1) : var_b;
+                running_var[c] = (1.f - momentum) * rv0[e] + momentum * (float)var_u;
+            }
+        }
+    }
+}
+
 // used by nsg_conv_forward_bnstats (conv_api.hip): merge the per-tile statistics the conv epilogue wrote
 int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, float eps, float momentum, float *mean,
                             float *invstd, float *running_mean, float *running_var, hipStream_t s)
 {
+    if (ntiles <= MAX_SLABS && C % 4 == 0) {
+        hipLaunchKernelGGL(bn_stats_tiles_onepass_kernel, dim3(C / 4), dim3(256), 0, s, tiles, ntiles, M, C, eps, momentum, mean, invstd,
+                           running_mean, running_var);
+        return nsg_check_launch("bn_stats_tiles_onepass_kernel");
+    }
     // the chunk records live behind the tile records (callers size the tile buffer with nsg_bn_tiles_bytes)
     double *chunks = reinterpret_cast<double *>(const_cast<float *>(tiles) + nsg_align_up((size_t)ntiles * 3 * C, 64));
     hipLaunchKernelGGL(bn_stats_tiles_fold_kernel, dim3(TILE_CHUNKS), dim3(256), 0, s, tiles, ntiles, C, chunks);
