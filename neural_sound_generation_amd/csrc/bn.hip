@@ -326,32 +326,42 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T *__restrict
 }
 
 // dbeta[c] = sum_s partial[s][c], dgamma[c] = sum_s partial[s][C + c]: one block per 4 channels, tree sums in double
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta)
+// colsum_partial != null: out3[c] = sum_s colsum_partial[s][c] in the same launch (slab_sum_final_kernel's job: a producer that
+// leaves both kinds of partials, the fused 1x1 backward, pays one finaliser launch instead of two)
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta,
+                                                           const float *__restrict__ colsum_partial, float *out3)
 {
     constexpr int PER = MAX_SLABS / 256;
     __shared__ double red[256];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * 4;
-    v4f a[PER], b[PER];
+    v4f a[PER], b[PER], c3[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int s = tid + 256 * i;
         const int sc = s < nslab ? s : nslab - 1;
         a[i] = *reinterpret_cast<const v4f *>(partial + (size_t)sc * 2 * C + c0);
         b[i] = *reinterpret_cast<const v4f *>(partial + (size_t)sc * 2 * C + C + c0);
+        c3[i] = colsum_partial ? *reinterpret_cast<const v4f *>(colsum_partial + (size_t)sc * C + c0) : v4f{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        double t1 = 0.0, t2 = 0.0;
+        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const bool ok = tid + 256 * i < nslab;
             t1 += ok ? (double)a[i][e] : 0.0;
             t2 += ok ? (double)b[i][e] : 0.0;
+            t3 += ok ? (double)c3[i][e] : 0.0;
         }
         const double s1 = block_sum256(t1, red, tid);
         const double s2 = block_sum256(t2, red, tid);
-        if (tid == 0 && c0 + e < C) { dbeta[c0 + e] = (float)s1; dgamma[c0 + e] = (float)s2; }
+        const double s3 = colsum_partial ? block_sum256(t3, red, tid) : 0.0;
+        if (tid == 0 && c0 + e < C) {
+            dbeta[c0 + e] = (float)s1;
+            dgamma[c0 + e] = (float)s2;
+            if (colsum_partial) out3[c0 + e] = (float)s3;
+        }
     }
 }
 
@@ -541,7 +551,16 @@ size_t nsg_bn_tiles_bytes(int64_t ntiles, int C)
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s)
 {
     if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "bn_bwd_final: %d slabs / %d channels not supported", nslab, C);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, nslab, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, nslab, C, dgamma, dbeta, (const float *)nullptr, (float *)nullptr);
+    return nsg_check_launch("bn_bwd_final_kernel");
+}
+
+// ... and the column sums of a second partial array [nslab][C] in the same launch
+int nsg_launch_bn_bwd_final_colsum(const float *partial, const float *colsum_partial, int nslab, int C, float *dgamma, float *dbeta,
+                                   float *colsum, hipStream_t s)
+{
+    if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "bn_bwd_final: %d slabs / %d channels not supported", nslab, C);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, nslab, C, dgamma, dbeta, colsum_partial, colsum);
     return nsg_check_launch("bn_bwd_final_kernel");
 }
 
@@ -641,14 +660,14 @@ int nsg_bn_backward(const void *x, const void *y_relu, const void *dy, const flo
     if (dtype == NSG_BF16) {
         typedef bf16_t T;
         hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
-        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta, (const float *)nullptr, (float *)nullptr);
         // the stage-1 partials have been consumed by bn_bwd_final (stream order): the buffer is reused for the dx column sums
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
                            dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
     } else {
         typedef float T;
         hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
-        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta, (const float *)nullptr, (float *)nullptr);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma,
                            dgamma, dbeta, relu_beta, (T *)dx, M, C, g.rows, inv_m, dx_colsum ? partial : nullptr);
     }
@@ -706,7 +725,7 @@ int nsg_bn_backward_sums(const void *x, const void *y_relu, const void *dy, cons
         typedef float T;
         hipLaunchKernelGGL((bn_bwd_partial_kernel<T>), dim3(g.nslab), dim3(256), 0, s, (const T *)x, (const T *)y_relu, (const T *)dy, mean, invstd, gamma, relu_beta, M, C, g.rows, partial);
     }
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, g.nslab, C, dgamma, dbeta, (const float *)nullptr, (float *)nullptr);
     return nsg_check_launch("bn_backward_sums");
 }
 

@@ -911,10 +911,7 @@ int nsg_bn_backward_conv1x1_dgrad_wgrad(const void *h, const void *dy, const flo
     int rc = nsg_launch_flat1x1_fused_bwd(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dx, dw, M, C, workspace, &nblocks, prev_x, prev_mean,
                                           prev_invstd, prev_gamma, prev_beta, &colsum_partial, &prev_partial, s);
     if (rc) return rc;
-    if (dh_colsum) {
-        rc = nsg_launch_slab_sum_final(colsum_partial, nblocks, C, dh_colsum, s);
-        if (rc) return rc;
-    }
+    if (dh_colsum) return nsg_launch_bn_bwd_final_colsum(prev_partial, colsum_partial, nblocks, C, prev_dgamma, prev_dbeta, dh_colsum, s);
     return nsg_launch_bn_bwd_final(prev_partial, nblocks, C, prev_dgamma, prev_dbeta, s);
 }
 

@@ -239,5 +239,8 @@ int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, fl
                             float *invstd, float *running_mean, float *running_var, hipStream_t s);
 // dbeta[c] = sum_s partial[s][0][c], dgamma[c] = sum_s partial[s][1][c] over nslab <= 1024 slabs of [2][C] (fixed order, double)
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s);
+// ... and colsum[c] = sum_s colsum_partial[s][c] in the same launch
+int nsg_launch_bn_bwd_final_colsum(const float *partial, const float *colsum_partial, int nslab, int C, float *dgamma, float *dbeta,
+                                   float *colsum, hipStream_t s);
 // out[c] = sum_s partial[s][c] over nslab <= 1024 slabs of [C] (fixed order, double)
 int nsg_launch_slab_sum_final(const float *partial, int nslab, int C, float *out, hipStream_t s);
