@@ -66,6 +66,46 @@ def cpu_baseline(D, K, T, threads, batch=4, warmup=1, steps=3):
     return batch * T / dt, dt
 
 
+LINE_LIMIT = 3072   # the driver keeps only the tail of stdout: the record must be ONE short line
+
+
+def build_line(*, value, ms_per_step, world, steps, warmup, dtype, D, K, B, T, roof=None, cpu=None, other=None, other_configs=None) -> str:
+    """The ONE JSON line of the bench contract, compact by construction (< LINE_LIMIT bytes; tests/test_bench_line.py).
+    Per-kernel tables never go in here: `write_kernel_tables` puts them in a side file and on stderr."""
+    line = {
+        "metric": "mel-frames/sec VQ-VAE fwd+bwd+Adam (80-mel x 1024)", "value": round(value, 1), "unit": "mel-frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: VQVAE(1,dim={D},z_dim={K}) train step, {B} clips/GPU x 80-mel x {T} frames",
+                   "clips_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}"},
+        "roofline": roof, "cpu_baseline": cpu, "other_mode": other, "other_configs": other_configs,
+    }
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # never let an addition push the head of the record out of the driver's window again
+        line["other_configs"] = None
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_kernel_tables(tables: dict) -> str:
+    """Per-kernel tables (launches per step, HIP-event time, algorithmic work, fraction of the bounding peak) go to
+    `bench_kernels.json` (under gpurun_out/ when that exists, else next to this script) and to stderr -- never on stdout."""
+    out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+    path = os.path.join(out_dir, "bench_kernels.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(tables, f, indent=1)
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+    for name, rows in tables.items():
+        print(f"[bench] kernels {name}:", file=sys.stderr)
+        for r in rows:
+            print("[bench]   " + json.dumps(r, separators=(",", ":")), file=sys.stderr)
+    sys.stderr.flush()
+    return path
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: start the N ranks ourselves, one fresh process per GPU with torchrun's
     environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  This parent makes no GPU call before or after (a
@@ -132,17 +172,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(dtype_name, steps, warmup, use_timer, D=D, K=K, B=B, census_steps=0):
+    def run_mode(dtype_name, steps, warmup, use_timer, D=D, K=K, B=B, census_steps=0, n_speakers=None):
         """Time `steps` training steps of the given compute mode.  Returns dict(value, ms, losses, gather (the dominant
         kernel's HIP-event summary over the timed region), census (per-kernel summary of `census_steps` extra steps taken
         AFTER the timed region with every entry-point call bracketed by events))."""
         torch.manual_seed(1)                       # src/main.py:43,71 -- identical init on every rank
         cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-        model = M.VQVAE(1, D, K, compute_dtype=cdtype).to(dev).train()
+        model = M.VQVAE(1, D, K, compute_dtype=cdtype, n_speakers=n_speakers).to(dev).train()
         step = FusedTrainStep(model, lr=1e-3, beta=1.0)
-        c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+        gen = torch.Generator().manual_seed(1234 + rank)
+        c = torch.rand(B, 1, 80, T, generator=gen).to(dev)
+        g = torch.randint(0, n_speakers, (B,), generator=gen).to(dev) if n_speakers else None
         for _ in range(warmup):
-            step.step(c)
+            step.step(c, g)
         timer = None
         if use_timer:
             timer = ops.KernelTimer()
@@ -150,7 +192,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            losses = step.step(c)
+            losses = step.step(c, g)
         sync()
         elapsed = time.perf_counter() - t0
         ops.KERNEL_TIMER = None
@@ -164,7 +206,7 @@ def main():
             cen = ops.KernelTimer()
             _lib.CENSUS = cen
             for _ in range(census_steps):
-                step.forward_backward(c)           # (no collective inside: the other ranks need not take part)
+                step.forward_backward(c, g)        # (no collective inside: the other ranks need not take part)
                 step.opt.step()
             torch.cuda.synchronize()
             _lib.CENSUS = None
@@ -176,8 +218,8 @@ def main():
     def _conv_kernel_name(dtype):
         """The kernel behind the conv forward / data-gradient launches that the in-region timer brackets (profiles/*_kernel_stats.csv rows)."""
         if dtype == "bf16":
-            return "patch_gemm_kernel<...> (gemm_patch.hip: every 3x3 / 4x4-s2 / transposed conv forward and data gradient, bf16 operands)"
-        return "gather_gemm_kernel<float, float, 128x128> (gemm_gather.hip: conv forward and data gradients, fp32 operands)"
+            return "patch_gemm_kernel (gemm_patch.hip: conv forward + data gradient, bf16)"
+        return "gather_gemm_kernel (gemm_gather.hip: conv forward + data gradient, fp32)"
 
     def kernel_table(census, dtype_name, ms_per_step):
         """One row per kernel group of the step: launches per step, HIP-event time per launch, algorithmic work per launch
@@ -202,43 +244,48 @@ def main():
         return rows
 
     main_run = run_mode(args.dtype, args.steps, args.warmup, not args.no_kernel_timer, census_steps=0 if args.no_kernel_timer else 3)
-    value, ms_per_step, loss_triple, s = main_run["value"], main_run["ms"], main_run["losses"], main_run["gather"]
+    value, ms_per_step, s = main_run["value"], main_run["ms"], main_run["gather"]
+    tables = {}
+    if main_run["census"]:
+        tables[f"configs[1] {args.dtype} B={B}"] = kernel_table(main_run["census"], args.dtype, ms_per_step)
     other = None
     if not args.no_second_mode:
         # the other compute mode, same shapes, a short run: fp32 = parity mode, bf16 = throughput mode
         od = "bf16" if args.dtype == "f32" else "f32"
         o = run_mode(od, max(3, args.steps // 4), 2, not args.no_kernel_timer, census_steps=0 if args.no_kernel_timer else 2)
-        other = {"dtype": od, "value": round(o["value"], 1), "unit": "mel-frames/s", "ms_per_step": round(o["ms"], 3), "losses": o["losses"]}
-        if o["gather"]:
-            opeak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
-            other["roofline"] = {"bound": "mfma", "kernel": _conv_kernel_name(od), "achieved": round(o["gather"]["tflops"], 2),
-                                 "peak": opeak, "unit": "TFLOP/s", "frac": round(o["gather"]["tflops"] / opeak, 4),
-                                 "step_frac": round(o["value"] * flops_per_frame(D, K) / 1e12 / opeak, 4)}
-            if o["census"]:
-                other["roofline"]["kernels"] = kernel_table(o["census"], od, o["ms"])
+        opeak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
+        other = {"dtype": od, "value": round(o["value"], 1), "ms_per_step": round(o["ms"], 3),
+                 "frac": round(o["gather"]["tflops"] / opeak, 4) if o["gather"] else None,
+                 "step_frac": round(o["value"] / world * flops_per_frame(D, K) / 1e12 / opeak, 4)}
+        if o["census"]:
+            tables[f"configs[1] {od} B={B}"] = kernel_table(o["census"], od, o["ms"])
     other_configs = None
     if not args.no_other_configs and world == 1 and (D, K) == (128, 512):
-        # BASELINE configs[3]: the large codebook (K = 8192, D = 256), 16 clips -- the config that stresses the distance
-        # contraction + argmin; both searches timed: the bit-exact fp32 one (parity mode) and the bf16x3 one (bf16 mode)
+        # the other single-GPU configurations of BASELINE.json, short runs:
+        #   configs[2]  speaker-conditioned decoder (7 speakers, hparams.py:84), K = 512, D = 128, same batch as the headline
+        #   configs[3]  the large codebook (K = 8192, D = 256), 16 clips: stresses the distance contraction + argmin; both
+        #               searches: the bit-exact fp32 one (parity mode) and the bf16x3 one (bf16 mode)
+        #   configs[4]  its per-GPU share on ONE GPU: 256 clips (the 8-GPU curve itself is the driver's to measure)
         other_configs = []
-        for od in ("bf16", "f32"):
-            o = run_mode(od, 5, 2, False, D=256, K=8192, B=16, census_steps=2)
+        plan = [("configs[2] 7 speakers", "bf16", 128, 512, B, 7, 5), ("configs[3] D=256 K=8192", "bf16", 256, 8192, 16, None, 5),
+                ("configs[3] D=256 K=8192", "f32", 256, 8192, 16, None, 5), ("configs[4] share: 256 clips", "bf16", 128, 512, 256, None, 4)]
+        for tag, od, d_, k_, b_, spk, st in plan:
+            o = run_mode(od, st, 2, False, D=d_, K=k_, B=b_, census_steps=2, n_speakers=spk)
             peak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
-            ent = {"workload": "BASELINE configs[3]: VQVAE(1, dim=256, z_dim=8192), 16 clips of 80-mel x %d frames, train step" % T,
-                   "dtype": od, "value": round(o["value"], 1), "unit": "mel-frames/s", "ms_per_step": round(o["ms"], 3), "losses": o["losses"],
-                   "algorithmic_tflops": round(o["value"] * flops_per_frame(256, 8192) / 1e12, 2),
-                   "step_frac": round(o["value"] * flops_per_frame(256, 8192) / 1e12 / peak, 4)}
+            ent = {"workload": tag, "dtype": od, "clips": b_, "value": round(o["value"], 1), "ms_per_step": round(o["ms"], 3),
+                   "step_frac": round(o["value"] * flops_per_frame(d_, k_) / 1e12 / peak, 4)}
             if o["census"]:
                 rows = kernel_table(o["census"], od, o["ms"])
+                tables[f"{tag} {od} B={b_}"] = rows
                 vq = [r for r in rows if r["kernel"].startswith("vq_forward")]
-                if vq:
-                    ent["vq_forward"] = vq[0]
-                ent["kernels"] = rows[:8]
+                if vq and k_ >= 4096:
+                    ent["vq_frac"] = vq[0]["frac"]
+                    ent["vq_share"] = vq[0]["share_of_step"]
             other_configs.append(ent)
 
     if rank == 0:
         roof = None
-        if s is not None:
+        if s:
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
             if os.path.exists(pmc) and (D, K, B, T) == (128, 512, 128, 1024):
@@ -247,42 +294,24 @@ def main():
                 ent = json.load(open(pmc)).get(args.dtype)
                 if ent:
                     traffic = round(ent["hbm_bytes_per_launch"] / 1e9, 3)
-            if s:
-                peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-                roof = {"bound": "mfma", "kernel": _conv_kernel_name(args.dtype), "achieved": round(s["tflops"], 2),
-                        "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
-                        "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/)", "launches": s["launches"], "avg_launch_ms": round(s["avg_ms"], 4),
-                        "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
-                        "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3),
-                        # the whole step against the same peak: algorithmic FLOP per second / MFMA peak
-                        "step_frac": round(value / world * flops_per_frame(D, K) / 1e12 / peak, 4)}
-                if main_run["census"]:
-                    roof["kernels"] = kernel_table(main_run["census"], args.dtype, ms_per_step)
-                    roof["kernels_note"] = ("per-kernel rows: HIP events around every C-ABI call over 3 extra steps taken right after the timed "
-                                            "region (same process, same tensors); the headline row above is timed INSIDE the timed region")
+            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": _conv_kernel_name(args.dtype), "achieved": round(s["tflops"], 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(s["tflops"] / peak, 4),
+                    "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/)", "launches": s["launches"],
+                    "avg_launch_ms": round(s["avg_ms"], 4), "gflop_per_launch": round(s["flops_per_launch"] / 1e9, 3),
+                    "share_of_step": round(s["total_ms"] / (ms_per_step * args.steps), 3),
+                    # the whole step against the same peak: algorithmic FLOP per second / MFMA peak
+                    "step_frac": round(value / world * flops_per_frame(D, K) / 1e12 / peak, 4)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is taken at N = 1 only
             threads = host_threads()
             v, dt = cpu_baseline(D, K, T, threads)
             cpu = {"value": round(v, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
-                   "sample": f"oracle/vqvae_oracle.py train_step, 4 clips x 80x{T}, 1 warm-up + 3 timed steps ({dt * 1e3:.0f} ms/step)"}
-        line = {
-            "metric": "mel-frames/sec VQ-VAE fwd+bwd+Adam (80-mel x 1024)", "value": round(value, 1), "unit": "mel-frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: VQVAE(1, dim={D}, z_dim={K}), {B} clips/GPU of 80-mel x {T} frames, "
-                                   f"train step (fwd + 3 losses + bwd + Adam{' + grad all-reduce' if world > 1 else ''})",
-                       "clips_per_gpu": B, "global_batch": B * world, "frames": T, "parallelism": f"dp{world}",
-                       "per_gpu_value": round(value / world, 1),
-                       "algorithmic_tflops": round(value * flops_per_frame(D, K) / 1e12, 2),
-                       "losses": loss_triple,
-                       "parity": ("bf16 storage: same computation at bf16 accuracy (tests/test_gpu_model.py::test_bf16_mode_*); the north_star "
-                                  "parity bar (bit-exact code indices, losses within 1e-5 of the reference CPU path) is met by the fp32 mode "
-                                  "timed in this same run (other_mode)") if args.dtype == "bf16" else
-                                 "fp32 parity mode: bit-exact code indices, losses within 1e-5 of the reference CPU path (tests/)"},
-            "roofline": roof, "cpu_baseline": cpu, "other_mode": other, "other_configs": other_configs,
-        }
-        print(json.dumps(line), flush=True)
+                   "sample": f"oracle train_step, 4 clips x 80x{T}, 1 warm-up + 3 timed steps ({dt * 1e3:.0f} ms/step)"}
+        if tables:
+            write_kernel_tables(tables)
+        print(build_line(value=value, ms_per_step=ms_per_step, world=world, steps=args.steps, warmup=args.warmup, dtype=args.dtype,
+                         D=D, K=K, B=B, T=T, roof=roof, cpu=cpu, other=other, other_configs=other_configs), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
