@@ -64,6 +64,9 @@ class FusedTrainStep:
         self.g_code = None if self.ema else self.opt.grads_for([self.codebook])[0]
         self.spk = getattr(model, "speaker_embedding", None)
         self.g_spk = self.opt.grads_for([self.spk.weight])[0] if self.spk is not None else None
+        # test hook: (N,) int64 code indices to use INSTEAD of the search's (the search still runs and is ignored).  Lets a test
+        # compare this mode's backward with another evaluation's on the SAME codes (tests/test_gpu_model.py, bf16 fidelity).
+        self.force_indices = None
 
     @torch.no_grad()
     def forward_backward(self, c: torch.Tensor, g: torch.Tensor | None = None):
@@ -87,7 +90,15 @@ class FusedTrainStep:
         # bf16 mode without speaker conditioning: z_q is never materialised in fp32 -- the search writes the decoder's
         # (ReLU'd, bf16) input itself, the losses read codebook[idx], the codebook gradient comes from per-code sums of z_e
         lean = LEAN_VQ and search == "bf16x3" and self.dtype == torch.bfloat16 and self.spk is None and D % 8 == 0
-        if lean:
+        if self.force_indices is not None:
+            idx = self.force_indices.view(-1).to(device=ze.device, dtype=torch.int64).contiguous()
+            if idx.numel() != ze.numel() // D:
+                raise ValueError("force_indices must hold one code index per latent row")
+            zq = ops.gather_rows(self.codebook.detach(), idx).view_as(ze)
+            zdec = zq
+            if lean:
+                zdec, zq = ops.convert(zq, self.dtype, relu=True), None
+        elif lean:
             idx, _, _, zdec = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=False, impl=search, codes_bf16="relu")
             zq = None
             zdec = zdec.view(ze.shape)
