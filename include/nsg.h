@@ -114,6 +114,14 @@ NSG_API size_t nsg_vq_bf16x3_workspace_bytes(int64_t N, int32_t D, int32_t K);
 NSG_API int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
                                   float *codes_out, float *dmin_out, void *codes_bf16_out, int32_t bf16_relu, void *workspace,
                                   size_t workspace_bytes, void *stream);
+/* The same with a per-clip conditioning row folded into the bf16 code write (BASELINE configs[2], the speaker-conditioned
+ * decoder; an extension: the reference loads the speaker id and ignores it, src/train.py:114): row n belongs to clip
+ * n / rows_per_clip and codes_bf16_out[n] = [relu]( e[idx[n]] + clip_rows[clip] ), clip_rows fp32 [clips][D].  idx_out,
+ * codes_out and dmin_out are unaffected.  clip_rows == NULL is nsg_vq_forward_bf16x3. */
+NSG_API int nsg_vq_forward_bf16x3_cond(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+                                       float *codes_out, float *dmin_out, void *codes_bf16_out, int32_t bf16_relu,
+                                       const float *clip_rows, int64_t rows_per_clip, void *workspace, size_t workspace_bytes,
+                                       void *stream);
 
 /* out[r] = torch.sum(v[r]**2) with ATen's CPU summation order (vector_quantization.py:12-13). */
 NSG_API int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream);

@@ -41,6 +41,7 @@ _SIGS = {
     "nsg_vq_forward": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_vq_bf16x3_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "nsg_vq_forward_bf16x3": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_vq_forward_bf16x3_cond": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_int32, _P, c_int64, _P, c_size_t, _P]),
     "nsg_debug_vq_forward_valu": (None, [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_rowsumsq": (None, [_P, c_int64, c_int32, _P, _P]),
     "nsg_index_add_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

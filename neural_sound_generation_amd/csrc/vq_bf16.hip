@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
                                                                 const float *__restrict__ x2, const float *__restrict__ c2,
                                                                 int64_t N, int D, int K, int64_t *__restrict__ idx_out,
                                                                 float *__restrict__ codes_out, float *__restrict__ dmin_out,
-                                                                bf16_t *__restrict__ codes_lp_out, int lp_relu)
+                                                                bf16_t *__restrict__ codes_lp_out, int lp_relu,
+                                                                const float *__restrict__ clip_rows, int64_t rows_per_clip)
 {
     constexpr int DP = 16 * NKS;
     constexpr int EPB = DP * 2 + 16;              // LDS row pitch in bytes: 16 rows -> 16 different 16-byte slots
@@ -193,6 +194,11 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
             const float *src = e + (size_t)sidx[r] * D + d8;
             const v4f a = *reinterpret_cast<const v4f *>(src), b = *reinterpret_cast<const v4f *>(src + 4);
             float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (clip_rows) {    // per-clip conditioning row (speaker embedding) added to every latent row of the clip, before the ReLU
+                const float *cr = clip_rows + (size_t)(row / rows_per_clip) * D + d8;
+                const v4f ca = *reinterpret_cast<const v4f *>(cr), cb = *reinterpret_cast<const v4f *>(cr + 4);
+                v[0] += ca.x; v[1] += ca.y; v[2] += ca.z; v[3] += ca.w; v[4] += cb.x; v[5] += cb.y; v[6] += cb.z; v[7] += cb.w;
+            }
             if (lp_relu) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -204,7 +210,8 @@ __global__ __launch_bounds__(256) void vq_forward_bf16x3_kernel(const float *__r
 
 template <int NKS>
 int launch(const float *x, const bf16_t *ehi, const bf16_t *elo, const float *e, const float *x2, const float *c2, int64_t N, int D,
-           int K, int64_t *idx, float *codes, float *dmin, bf16_t *codes_lp, int lp_relu, hipStream_t s)
+           int K, int64_t *idx, float *codes, float *dmin, bf16_t *codes_lp, int lp_relu, const float *clip_rows, int64_t rows_per_clip,
+           hipStream_t s)
 {
     constexpr int DP = 16 * NKS;
     const size_t lds = (size_t)2 * 2 * 32 * (DP * 2 + 16);
@@ -216,8 +223,8 @@ int launch(const float *x, const bf16_t *ehi, const bf16_t *elo, const float *e,
                                              reinterpret_cast<const void *>(&vq_forward_bf16x3_kernel<NKS, false>)}, lds, "vq_forward_bf16x3");
         if (rc != NSG_OK) return rc;
     }
-    if (x2) hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS, true>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
-    else    hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS, false>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu);
+    if (x2) hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS, true>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu, clip_rows, rows_per_clip);
+    else    hipLaunchKernelGGL((vq_forward_bf16x3_kernel<NKS, false>), dim3((unsigned)nb), dim3(256), lds, s, x, ehi, elo, e, x2, c2, N, D, K, idx, codes, dmin, codes_lp, lp_relu, clip_rows, rows_per_clip);
     return nsg_check_launch("vq_forward_bf16x3_kernel");
 }
 
@@ -237,7 +244,17 @@ size_t nsg_vq_bf16x3_workspace_bytes(int64_t N, int32_t D, int32_t K)
 int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out, float *codes_out,
                           float *dmin_out, void *codes_bf16_out, int32_t bf16_relu, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return nsg_vq_forward_bf16x3_cond(x, e, N, D, K, idx_out, codes_out, dmin_out, codes_bf16_out, bf16_relu, nullptr, 0, workspace,
+                                      workspace_bytes, stream);
+}
+
+int nsg_vq_forward_bf16x3_cond(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out, float *codes_out,
+                               float *dmin_out, void *codes_bf16_out, int32_t bf16_relu, const float *clip_rows, int64_t rows_per_clip,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
     NSG_REQUIRE(x && e && idx_out && N >= 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_vq_forward_bf16x3: bad argument");
+    NSG_REQUIRE(!clip_rows || (codes_bf16_out && rows_per_clip > 0 && nsg_aligned16(clip_rows)), NSG_E_INVALID,
+                "nsg_vq_forward_bf16x3_cond: clip_rows needs codes_bf16_out, rows_per_clip > 0 and 16-byte alignment");
     NSG_REQUIRE(D <= 256 && D % 8 == 0, NSG_E_UNSUPPORTED, "nsg_vq_forward_bf16x3: D=%d must be a multiple of 8, at most 256", D);
     NSG_REQUIRE(nsg_aligned16(x) && nsg_aligned16(e) && (!codes_out || nsg_aligned16(codes_out)) && (!codes_bf16_out || nsg_aligned16(codes_bf16_out)),
                 NSG_E_INVALID, "nsg_vq_forward_bf16x3: pointers must be 16-byte aligned");
@@ -266,11 +283,11 @@ int nsg_vq_forward_bf16x3(const float *x, const float *e, int64_t N, int32_t D, 
     rc = nsg_check_launch("split_bf16_kernel");
     if (rc) return rc;
     switch (DP) {
-    case 16:  return launch<1>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
-    case 32:  return launch<2>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
-    case 64:  return launch<4>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
-    case 128: return launch<8>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
-    default:  return launch<16>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, s);
+    case 16:  return launch<1>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, clip_rows, rows_per_clip, s);
+    case 32:  return launch<2>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, clip_rows, rows_per_clip, s);
+    case 64:  return launch<4>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, clip_rows, rows_per_clip, s);
+    case 128: return launch<8>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, clip_rows, rows_per_clip, s);
+    default:  return launch<16>(x, ehi, elo, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, lp, bf16_relu, clip_rows, rows_per_clip, s);
     }
 }
 

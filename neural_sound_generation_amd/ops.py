@@ -134,13 +134,18 @@ def _gemm_flops(d: "ConvDesc") -> float:
 # ------------------------------------------------------------------------------------------------
 # vector quantiser
 # ------------------------------------------------------------------------------------------------
-def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", codes_bf16=None):
+def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", codes_bf16=None, clip_rows=None):
     """x2d (N,D), codebook (K,D) -> idx (N,) int64 [, codes (N,D)] [, dmin (N,)]
     impl: "mfma" = the bit-exact fp32 search (parity mode); "valu" = its vector-ALU cross-check; "bf16x3" = the bf16
     mode's search on the bf16 matrix pipe with split operands (relative distance error ~2^-16: near-ties may differ).
     codes_bf16 ("plain" | "relu", bf16x3 only): also return the code rows as a bf16 (N,D) tensor (ReLU'd: the decoder's
-    input after its leading ReLU) as a 4th result."""
+    input after its leading ReLU) as a 4th result.  clip_rows (B, D) fp32 (with codes_bf16): a per-clip conditioning row added
+    to every bf16 code row of that clip before the ReLU (N = B * rows per clip; the speaker-conditioned decoder)."""
     _chk(x2d, "x"); _chk(codebook, "codebook")
+    if clip_rows is not None:
+        _chk(clip_rows, "clip_rows")
+        if impl != "bf16x3" or not codes_bf16 or clip_rows.shape[1] != x2d.shape[1] or x2d.shape[0] % clip_rows.shape[0] != 0:
+            raise ValueError("vq_forward: clip_rows needs impl='bf16x3', codes_bf16 and (B, D) rows with N a multiple of B")
     N, D = x2d.shape
     K, D2 = codebook.shape
     if D != D2:
@@ -156,8 +161,13 @@ def vq_forward(x2d, codebook, want_codes=True, want_dist=False, impl="mfma", cod
         if impl == "bf16x3":
             lp = torch.empty(N, D, dtype=torch.bfloat16, device=x2d.device) if codes_bf16 else None
             _lib.tag("vq_forward_bf16x3 (search + gather)", 2.0 * N * K * D)
-            _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin), _p(lp),
-                      c_int32(1 if codes_bf16 == "relu" else 0), _p(ws), c_size_t(nb), _stream())
+            if clip_rows is not None:
+                _lib.call("nsg_vq_forward_bf16x3_cond", _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin),
+                          _p(lp), c_int32(1 if codes_bf16 == "relu" else 0), _p(clip_rows), c_int64(N // clip_rows.shape[0]), _p(ws),
+                          c_size_t(nb), _stream())
+            else:
+                _lib.call(fn, _p(x2d), _p(codebook), c_int64(N), c_int32(D), c_int32(K), _p(idx), _p(codes), _p(dmin), _p(lp),
+                          c_int32(1 if codes_bf16 == "relu" else 0), _p(ws), c_size_t(nb), _stream())
             if codes_bf16:
                 return idx, codes, dmin, lp
             return idx, codes, dmin

@@ -87,9 +87,14 @@ class FusedTrainStep:
         D = ze.shape[-1]
         K = self.codebook.shape[0]
         search = getattr(self.model.codebook, "search_impl", "mfma")
-        # bf16 mode without speaker conditioning: z_q is never materialised in fp32 -- the search writes the decoder's
-        # (ReLU'd, bf16) input itself, the losses read codebook[idx], the codebook gradient comes from per-code sums of z_e
-        lean = LEAN_VQ and search == "bf16x3" and self.dtype == torch.bfloat16 and self.spk is None and D % 8 == 0
+        # bf16 mode: z_q is never materialised in fp32 -- the search writes the decoder's (ReLU'd, bf16) input itself, with the
+        # clip's speaker row added when the decoder is speaker-conditioned; the losses read codebook[idx], the codebook gradient
+        # comes from per-code sums of z_e
+        lean = LEAN_VQ and search == "bf16x3" and self.dtype == torch.bfloat16 and D % 8 == 0
+        spk_rows = None
+        if self.spk is not None and g is not None:
+            g = g.view(-1).to(torch.int64).contiguous()
+            spk_rows = ops.gather_rows(self.spk.weight.detach(), g)          # (B, D) fp32
         if self.force_indices is not None:
             idx = self.force_indices.view(-1).to(device=ze.device, dtype=torch.int64).contiguous()
             if idx.numel() != ze.numel() // D:
@@ -97,18 +102,19 @@ class FusedTrainStep:
             zq = ops.gather_rows(self.codebook.detach(), idx).view_as(ze)
             zdec = zq
             if lean:
-                zdec, zq = ops.convert(zq, self.dtype, relu=True), None
+                zdec = ops.add_per_clip(zq, spk_rows) if spk_rows is not None else zq
+                zdec, zq = ops.convert(zdec, self.dtype, relu=True), None
         elif lean:
-            idx, _, _, zdec = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=False, impl=search, codes_bf16="relu")
+            idx, _, _, zdec = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=False, impl=search, codes_bf16="relu",
+                                             clip_rows=spk_rows)
             zq = None
             zdec = zdec.view(ze.shape)
         else:
             idx, zq, _ = ops.vq_forward(ze.view(-1, D), self.codebook.detach(), want_codes=True, impl=search)
             zq = zq.view_as(ze)
             zdec = zq
-        if self.spk is not None and g is not None:
-            g = g.view(-1).to(torch.int64).contiguous()
-            zdec = ops.add_per_clip(zq, ops.gather_rows(self.spk.weight.detach(), g), out_dtype=self.dtype)
+        if spk_rows is not None and not lean:
+            zdec = ops.add_per_clip(zq, spk_rows, out_dtype=self.dtype)
         # loss_recons = mse(zero-pad(x_tilde), c) and d/dx_tilde             (train.py:118-129)
         xt, ds = engine.decoder_forward(zdec, self.decP, True, dtype=self.dtype, packs=dec_packs, zq_is_relu=lean, mse_target=x,
                                         mse_dbias=self.g_dec[21])

@@ -159,29 +159,27 @@ def test_tiny_model_autograd_step(golden_dir, si):
     np.testing.assert_allclose(x_tilde.detach().cpu().numpy(), g[tag + "x_tilde"], rtol=1e-4, atol=5e-6)
     idx = model.codebook(z_e.detach()).cpu().numpy()
     flips = index_flips_are_near_ties(idx, g[tag + "idx"], g[tag + "z_e"], g["sd0.codebook.embedding.weight"])
-    assert flips <= max(1, idx.size // 500), f"{flips} index flips"
+    assert flips == 0, f"{flips} index flips: the fixture batch is deterministic and every code must match (the gradient checks below need it)"
     named = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
-    if flips == 0:
-        for k, got in named.items():
-            if is_noise_bias(k):
-                assert_noise_bias(k, got, named)
-                continue
-            want = g[tag + "grad." + k]
-            scale = max(np.abs(want).max(), 1e-8)
-            err = np.abs(got - want).max()
-            assert err <= 2e-4 * scale + 1e-8, f"grad {k}: err {err:.3e} scale {scale:.3e}"
+    for k, got in named.items():
+        if is_noise_bias(k):
+            assert_noise_bias(k, got, named)
+            continue
+        want = g[tag + "grad." + k]
+        scale = max(np.abs(want).max(), 1e-8)
+        err = np.abs(got - want).max()
+        assert err <= 2e-4 * scale + 1e-8, f"grad {k}: err {err:.3e} scale {scale:.3e}"
     opt.step()
     sd = model.state_dict()
     for k in ("encoder.1.running_mean", "encoder.1.running_var", "decoder.4.running_var", "encoder.5.block.5.running_mean"):
         np.testing.assert_allclose(sd[k].cpu().numpy(), g[tag + "sd1." + k], rtol=1e-4, atol=1e-6, err_msg=k)
     assert int(sd["encoder.1.num_batches_tracked"]) == 1
-    if flips == 0:
-        for k, p in model.named_parameters():
-            if is_noise_bias(k):
-                continue  # Adam turns round-off-sized gradients into +-lr steps
-            gk = np.abs(g[tag + "grad." + k])
-            big = gk > 1e-5
-            np.testing.assert_allclose(p.detach().cpu().numpy()[big], g[tag + "sd1." + k][big], rtol=0, atol=5e-6, err_msg=k)
+    for k, p in model.named_parameters():
+        if is_noise_bias(k):
+            continue  # Adam turns round-off-sized gradients into +-lr steps
+        gk = np.abs(g[tag + "grad." + k])
+        big = gk > 1e-5
+        np.testing.assert_allclose(p.detach().cpu().numpy()[big], g[tag + "sd1." + k][big], rtol=0, atol=5e-6, err_msg=k)
 
 
 @pytest.mark.parametrize("flat_adam", [False, True])
@@ -225,21 +223,20 @@ def test_reference_train_step_statement_for_statement(golden_dir, si, flat_adam)
     np.testing.assert_allclose(x_tilde.detach().cpu().numpy(), g[tag + "x_tilde"], rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(z_e_x.detach().cpu().numpy(), g[tag + "z_e"], rtol=1e-4, atol=5e-6)
     flips = index_flips_are_near_ties(idx, g[tag + "idx"], g[tag + "z_e"], g["sd0.codebook.embedding.weight"])
-    assert flips <= max(1, idx.size // 500), f"{flips} index flips"
-    if flips == 0:
-        np.testing.assert_allclose(z_q_x.detach().cpu().numpy(), g[tag + "z_q"], rtol=1e-5, atol=1e-7)
-        for k, got in named.items():
-            if is_noise_bias(k):
-                assert_noise_bias(k, got, named)
-                continue
-            want = g[tag + "grad." + k]
-            scale = max(np.abs(want).max(), 1e-8)
-            assert np.abs(got - want).max() <= 2e-4 * scale + 1e-8, f"grad {k}"
-        for k, p in model.named_parameters():
-            if is_noise_bias(k):
-                continue
-            big = np.abs(g[tag + "grad." + k]) > 1e-5
-            np.testing.assert_allclose(p.detach().cpu().numpy()[big], g[tag + "sd1." + k][big], rtol=0, atol=5e-6, err_msg=k)
+    assert flips == 0, f"{flips} index flips: bit-exact code indices are the bar, and the gradient / update checks below need them"
+    np.testing.assert_allclose(z_q_x.detach().cpu().numpy(), g[tag + "z_q"], rtol=1e-5, atol=1e-7)
+    for k, got in named.items():
+        if is_noise_bias(k):
+            assert_noise_bias(k, got, named)
+            continue
+        want = g[tag + "grad." + k]
+        scale = max(np.abs(want).max(), 1e-8)
+        assert np.abs(got - want).max() <= 2e-4 * scale + 1e-8, f"grad {k}"
+    for k, p in model.named_parameters():
+        if is_noise_bias(k):
+            continue
+        big = np.abs(g[tag + "grad." + k]) > 1e-5
+        np.testing.assert_allclose(p.detach().cpu().numpy()[big], g[tag + "sd1." + k][big], rtol=0, atol=5e-6, err_msg=k)
     sd = model.state_dict()
     for k in ("encoder.1.running_mean", "encoder.1.running_var", "decoder.4.running_var", "encoder.5.block.5.running_mean"):
         np.testing.assert_allclose(sd[k].cpu().numpy(), g[tag + "sd1." + k], rtol=1e-4, atol=1e-6, err_msg=k)
@@ -282,9 +279,8 @@ def test_tiny_eval_encode_decode(golden_dir):
     np.testing.assert_allclose(x_tilde.cpu().numpy(), g["eval.x_tilde"], rtol=1e-4, atol=2e-6)
     assert lat.dtype == torch.int64 and tuple(lat.shape) == g["eval.latents"].shape
     flips = int((lat.cpu().numpy() != g["eval.latents"]).sum())
-    assert flips <= max(1, lat.numel() // 500)
-    if flips == 0:
-        np.testing.assert_allclose(dec.cpu().numpy(), g["eval.decode"], rtol=1e-4, atol=2e-6)
+    assert flips == 0, f"{flips} latents differ from the reference's"
+    np.testing.assert_allclose(dec.cpu().numpy(), g["eval.decode"], rtol=1e-4, atol=2e-6)
     assert rel(F.mse_loss(z_q, z_e).item(), float(g["eval.loss_vq"])) < LOSS_RTOL
 
 
@@ -343,16 +339,15 @@ def test_cfg1_model_step(golden_dir):
     for got, want in zip(l, g["s0.losses"]):
         assert rel(got.item(), want) < LOSS_RTOL
     flips = int((step.last_indices.cpu().numpy() != g["s0.idx"].reshape(-1)).sum())
-    assert flips <= max(1, g["s0.idx"].size // 500), f"{flips} index flips"
-    if flips == 0:
-        named = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
-        for k, p in model.named_parameters():
-            if is_noise_bias(k):
-                assert_noise_bias(k, named[k], named)
-                continue
-            want = float(g["s0.gnorm." + k])
-            got = p.grad.double().norm().item()
-            assert abs(got - want) <= 2e-4 * want + 1e-7, f"{k}: {got} vs {want}"
+    assert flips == 0, f"{flips} index flips against the reference's indices for this batch"
+    named = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+    for k, p in model.named_parameters():
+        if is_noise_bias(k):
+            assert_noise_bias(k, named[k], named)
+            continue
+        want = float(g["s0.gnorm." + k])
+        got = p.grad.double().norm().item()
+        assert abs(got - want) <= 2e-4 * want + 1e-7, f"{k}: {got} vs {want}"
 
 
 @pytest.mark.parametrize("fused_stats", [False, True])
@@ -372,7 +367,10 @@ def test_full_width_step_against_oracle(dim, z_dim, B, T, fused_stats):
     c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(1234))
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     rec = O.forward_backward(st0, c)
-    rec64 = O.forward_backward(O.clone_state({k: (v.double() if v.is_floating_point() else v) for k, v in st0.items()}), c.double())
+    # the fp64 evaluation of the SAME piecewise branch: the fp32 oracle's code indices forced in (an fp64 search would pick other
+    # codes on the near-tie rows and the comparison below would be between two different functions)
+    rec64 = O.forward_backward(O.clone_state({k: (v.double() if v.is_floating_point() else v) for k, v in st0.items()}), c.double(),
+                               force_idx=rec["idx"])
     prev = engine.FUSED_BN_STATS
     engine.FUSED_BN_STATS = fused_stats
     try:
@@ -383,7 +381,8 @@ def test_full_width_step_against_oracle(dim, z_dim, B, T, fused_stats):
         assert rel(l[1].item(), rec["loss_vq"].item()) < LOSS_RTOL
         idx_ref = rec["idx"].numpy()
         flips = int((step.last_indices.cpu().numpy() != idx_ref).sum())
-        assert flips <= max(2, idx_ref.size // 500), f"{flips}/{idx_ref.size} index flips"
+        # deterministic inputs on deterministic arithmetic: observed 0 on MI355X for both shapes; the gradient check needs 0
+        assert flips == 0, f"{flips}/{idx_ref.size} code indices differ from the CPU oracle's"
         # determinism of the whole step: same inputs -> identical gradient bucket
         g1 = step.opt.flat_grad.clone()
         model2 = M.VQVAE(1, dim, z_dim)
@@ -393,15 +392,19 @@ def test_full_width_step_against_oracle(dim, z_dim, B, T, fused_stats):
         assert torch.equal(g1, step2.opt.flat_grad), "the training step must be bitwise reproducible"
     finally:
         engine.FUSED_BN_STATS = prev
-    if flips == 0 and bool((rec64["idx"] == rec["idx"]).all()):
-        for k, p in model.named_parameters():
-            if is_noise_bias(k):
-                continue
-            truth = rec64["grads"][k]
-            tn = max(truth.norm().item(), 1e-12)
-            err_gpu = (p.grad.double().cpu() - truth).norm().item() / tn
-            err_cpu = (rec["grads"][k].double() - truth).norm().item() / tn
-            assert err_gpu <= 4.0 * err_cpu + 1e-4, f"{k}: GPU {err_gpu:.2e} vs CPU-fp32 {err_cpu:.2e} (relative L2 distance to the fp64 result)"
+    assert bool((rec64["idx"] == rec["idx"]).all())
+    checked = 0
+    for k, p in model.named_parameters():
+        if is_noise_bias(k):
+            continue
+        truth = rec64["grads"][k]
+        tn = max(truth.norm().item(), 1e-12)
+        err_gpu = (p.grad.double().cpu() - truth).norm().item() / tn
+        err_cpu = (rec["grads"][k].double() - truth).norm().item() / tn
+        assert err_gpu <= 4.0 * err_cpu + 1e-4, f"{k}: GPU {err_gpu:.2e} vs CPU-fp32 {err_cpu:.2e} (relative L2 distance to the fp64 result)"
+        checked += 1
+    print(f"full width ({dim}, {z_dim}): 0 index flips, {checked} gradient tensors checked against the fp64 evaluation of the same codes")
+    assert checked == 27
 
 
 def test_large_codebook_step_against_oracle():
@@ -429,7 +432,7 @@ def test_large_codebook_step_against_oracle():
     idx_gpu = step.last_indices.cpu().numpy()
     flips = index_flips_are_near_ties(idx_gpu, idx_ref, rec["z_e"].numpy(), st0["codebook.embedding.weight"].numpy(), tol=2e-6)
     print(f"configs[3] fp32: {flips}/{idx_ref.size} indices differ from the CPU oracle, all fp64 near-ties")
-    assert flips <= idx_ref.size // 25, f"{flips}/{idx_ref.size} index flips"
+    assert flips <= 8, f"{flips}/{idx_ref.size} index flips (observed on MI355X: 0)"
     # the search on the ORACLE's encoder output is bit-exact (same rows, same codebook: no conv noise in between)
     ze_rows = rec["z_e"].permute(0, 2, 3, 1).reshape(-1, dim).contiguous()
     idx_same, _, _ = ops.vq_forward(ze_rows.to(DEV), st0["codebook.embedding.weight"].to(DEV), want_codes=False)
@@ -440,8 +443,14 @@ def test_large_codebook_step_against_oracle():
     # blocking; scripts/grad_accuracy_table.py, scripts/op_accuracy_probe.py: every operator alone is good to 1e-7).  At
     # the headline shape (D=128, two clips) the CPU oracle and the GPU both land at 1-3e-3 on the deepest tensors; here,
     # one clip, the CPU oracle happens to land at 1e-6, so "a small multiple of the CPU's distance" has a 5e-3 floor.
-    rec64 = O.forward_backward(O.clone_state({k: (v.double() if v.is_floating_point() else v) for k, v in st0.items()}), c.double())
-    exact = flips == 0 and bool((rec64["idx"] == rec["idx"]).all())
+    # fp64 on the SAME codes (the fp32 oracle's, forced in: an fp64 search disagrees with ANY fp32 search on ~1 % of the rows
+    # at this codebook size, SURVEY.md section 7, and would evaluate a different piecewise branch)
+    rec64 = O.forward_backward(O.clone_state({k: (v.double() if v.is_floating_point() else v) for k, v in st0.items()}), c.double(),
+                               force_idx=rec["idx"])
+    exact = flips == 0
+    print("configs[3] fp32 gradient check:", "exact branch (same codes as the oracle): every tensor within max(4x the CPU oracle's own "
+          "distance to fp64, 5e-3)" if exact else f"{flips} rows on other codes: every tensor within 2e-2 of fp64")
+    checked = 0
     for k, p in model.named_parameters():
         if is_noise_bias(k):
             continue
@@ -449,10 +458,10 @@ def test_large_codebook_step_against_oracle():
         tn = max(truth.norm().item(), 1e-12)
         err_gpu = (p.grad.double().cpu() - truth).norm().item() / tn
         err_cpu = (rec["grads"][k].double() - truth).norm().item() / tn
-        if exact:
-            assert err_gpu <= max(4.0 * err_cpu + 1e-4, 5e-3), f"{k}: GPU {err_gpu:.2e} vs CPU-fp32 {err_cpu:.2e} (relative L2 distance to the fp64 result)"
-        elif k.startswith("decoder."):
-            assert err_gpu < 2e-2, f"{k}: relative L2 distance {err_gpu:.3e} to the fp64 gradient"
+        bound = max(4.0 * err_cpu + 1e-4, 5e-3) if exact else 2e-2        # encoder AND decoder tensors in both branches
+        assert err_gpu <= bound, f"{k}: GPU {err_gpu:.2e} vs CPU-fp32 {err_cpu:.2e} (relative L2 distance to the fp64 result, bound {bound:.1e})"
+        checked += 1
+    assert checked == 27
     g1 = step.opt.flat_grad.clone()
     model2 = M.VQVAE(1, dim, z_dim)
     model2.load_state_dict(st0)
@@ -507,16 +516,9 @@ def test_ema_codebook_mode_and_data_parallel_identity():
     assert not torch.equal(before, model.codebook.embedding.weight.detach())
 
 
-def test_speaker_conditioned_decoder():
-    """Speaker embedding added to the decoder input (extension, BASELINE configs[2]; parity unpinned: the
-    reference ignores g).  Checked against CPU autograd of the same definition, and fused == autograd."""
-    torch.manual_seed(1)
-    D, K, S = 16, 32, 7
-    model = M.VQVAE(1, D, K, n_speakers=S)
-    st0 = {k: v.clone() for k, v in model.state_dict().items()}
-    c = torch.rand(4, 1, 80, 32, generator=torch.Generator().manual_seed(7))
-    g = torch.tensor([3, 0, 3, 6])
-    # CPU definition: oracle encoder / quantiser / decoder with the embedding rows added per clip
+def _speaker_oracle(st0, c, g):
+    """CPU definition of the speaker-conditioned step: oracle encoder / quantiser / decoder with the clip's embedding row
+    added to every latent pixel of the decoder input; autograd gives the embedding's gradient."""
     ost = O.clone_state({k: v for k, v in st0.items() if not k.startswith("speaker_embedding")})
     emb = st0["speaker_embedding.weight"].clone().requires_grad_(True)
     z_e = O.encoder(c, ost, True, {})
@@ -524,10 +526,26 @@ def test_speaker_conditioned_decoder():
     x_t = O.decoder(zq_st + emb[g][:, :, None, None], ost, True, {})
     lr_, lv, lc = O.loss_terms(c, x_t, z_e, zq_bar)
     (gemb,) = torch.autograd.grad(lr_ + lv + lc, [emb])
+    return lr_, lv, idx, gemb
+
+
+@pytest.mark.parametrize("D,K,S,B,T", [(16, 32, 7, 4, 32), (128, 512, 7, 2, 1024)])    # the second: BASELINE configs[2]'s widths
+def test_speaker_conditioned_decoder(D, K, S, B, T):
+    """Speaker embedding added to the decoder input (extension, BASELINE configs[2]: K = 512, D = 128, 7 speakers as in
+    hparams.py:84; parity unpinned: the reference loads g and ignores it, src/train.py:114).  fp32 mode against CPU autograd
+    of the same definition, and fused == autograd."""
+    torch.manual_seed(1)
+    model = M.VQVAE(1, D, K, n_speakers=S)
+    st0 = {k: v.clone() for k, v in model.state_dict().items()}
+    c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(7))
+    g = torch.tensor([3, 0, 3, 6][:B])
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    lr_, lv, idx, gemb = _speaker_oracle(st0, c, g)
     model = model.to(DEV).train()
     step = FusedTrainStep(model, lr=1e-3)
     l = step.forward_backward(c.to(DEV), g.to(DEV))
-    assert rel(l[0].item(), lr_.item()) < LOSS_RTOL
+    assert rel(l[0].item(), lr_.item()) < LOSS_RTOL and rel(l[1].item(), lv.item()) < LOSS_RTOL
+    assert int((step.last_indices.cpu() != idx).sum()) == 0
     got = model.speaker_embedding.weight.grad.cpu()
     assert float(got[1].abs().max()) == 0.0                      # speakers absent from the batch get no gradient
     np.testing.assert_allclose(got.numpy(), gemb.numpy(), rtol=2e-4, atol=2e-4 * float(gemb.abs().max()))
@@ -539,6 +557,51 @@ def test_speaker_conditioned_decoder():
     l3 = vqvae_loss_terms(c.to(DEV), xt, ze, zq)
     (l3[0] + l3[1] + l3[2]).backward()
     np.testing.assert_allclose(m2.speaker_embedding.weight.grad.cpu().numpy(), got.numpy(), rtol=1e-4, atol=1e-5 * float(got.abs().max()) + 1e-9)
+
+
+def test_speaker_conditioned_decoder_bf16_stays_on_the_fused_path(monkeypatch):
+    """configs[2] in the bf16 mode: with a speaker table the step keeps the quantiser's fused write of the decoder input (the
+    clip's embedding row is added inside nsg_vq_forward_bf16x3_cond; round 2 fell back to an fp32 z_q + a separate add pass).
+    Checked: the fused write == codebook[idx] + row -> ReLU -> bf16 exactly; the step equals the unfused form (same codes, losses
+    1e-5, speaker gradient 1e-3); against the fp32 CPU definition at bf16 accuracy."""
+    from neural_sound_generation_amd import train as T_
+    D, K, S, B, T = 128, 512, 7, 2, 1024
+    torch.manual_seed(1)
+    model = M.VQVAE(1, D, K, n_speakers=S, compute_dtype=torch.bfloat16)
+    st0 = {k: v.clone() for k, v in model.state_dict().items()}
+    c = torch.rand(B, 1, 80, T, generator=torch.Generator().manual_seed(7))
+    g = torch.tensor([5, 2])
+    # op level: the conditioned write
+    x = torch.randn(B * 640, D, generator=torch.Generator().manual_seed(3)).to(DEV) * 0.01
+    cb, rows = st0["codebook.embedding.weight"].to(DEV), st0["speaker_embedding.weight"][g].contiguous().to(DEV)
+    idx, _, _, lp = ops.vq_forward(x, cb, want_codes=False, impl="bf16x3", codes_bf16="relu", clip_rows=rows)
+    want = torch.relu(cb[idx].view(B, 640, D) + rows[:, None, :]).to(torch.bfloat16).view(-1, D)
+    assert torch.equal(lp, want)
+    idx2, _, _, lp2 = ops.vq_forward(x, cb, want_codes=False, impl="bf16x3", codes_bf16="relu")
+    assert torch.equal(idx, idx2) and torch.equal(lp2, torch.relu(cb[idx]).to(torch.bfloat16))
+
+    def run(lean):
+        monkeypatch.setattr(T_, "LEAN_VQ", lean)
+        m = M.VQVAE(1, D, K, n_speakers=S, compute_dtype=torch.bfloat16)
+        m.load_state_dict(st0)
+        m = m.to(DEV).train()
+        st = FusedTrainStep(m, lr=1e-3)
+        l = st.forward_backward(c.to(DEV), g.to(DEV))
+        return [x_.item() for x_ in l], st.last_indices.clone(), m.speaker_embedding.weight.grad.clone(), st
+    lf, idf, gf, stf = run(True)
+    lu, idu, gu, _ = run(False)
+    assert torch.equal(idf, idu)
+    assert rel(lf[0], lu[0]) < 1e-5 and rel(lf[1], lu[1]) < 1e-5
+    assert float((gf - gu).norm() / gu.norm()) < 1e-3
+    assert float(gf[0].abs().max()) == 0.0 and float(gf[5].abs().max()) > 0.0
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    lr_, lv, idx_ref, gemb = _speaker_oracle(st0, c, g)
+    assert rel(lf[0], lr_.item()) < 2e-2 and rel(lf[1], lv.item()) < 2e-2
+    cos = float(torch.dot(gf.cpu().double().flatten(), gemb.double().flatten()) / (gf.cpu().double().norm() * gemb.double().norm()))
+    print(f"configs[2] bf16: speaker-embedding gradient cosine vs the fp32 definition {cos:.4f}")
+    assert cos > 0.9
+    stf.step(c.to(DEV), g.to(DEV))          # and a full step (Adam moves the table)
+    assert not torch.equal(stf.model.speaker_embedding.weight.detach().cpu(), st0["speaker_embedding.weight"])
 
 
 def test_module_surface_on_gpu():
@@ -583,6 +646,31 @@ def test_bf16_mode_against_fp32_oracle(dim, z_dim, B, T):
     print("bf16 mode decoder gradient cosines vs fp32:", {k: round(v, 3) for k, v in cosines.items()})
     vals = sorted(cosines.values())
     assert vals[len(vals) // 2] > 0.97 and vals[0] > 0.6, cosines   # direction preserved; the layers right behind the ~2 % flipped codes deviate most
+    # Where that deviation comes from: the same step on the ORACLE's codes (FusedTrainStep.force_indices), so that no
+    # difference is due to the ~2 % of near-tie rows the bf16 encoder resolves differently.  What remains is the backward at
+    # bf16 storage accuracy: every tensor's gradient stays aligned with the fp32 one (scripts/bf16_grad_fidelity.py prints the
+    # table: relative L2 grows ~7x per BatchNorm backward crossed, the same amplification the fp32 evaluations show against
+    # fp64 at 2^-16 of the size; switching the fused layers off changes nothing).
+    mf = M.VQVAE(1, dim, z_dim, compute_dtype=torch.bfloat16)
+    mf.load_state_dict(st0)
+    mf = mf.to(DEV).train()
+    sf = FusedTrainStep(mf, lr=1e-3)
+    sf.force_indices = rec["idx"].reshape(-1).to(DEV)
+    lf = sf.forward_backward(c.to(DEV))
+    assert torch.equal(sf.last_indices.cpu(), rec["idx"].reshape(-1))
+    assert rel(lf[0].item(), rec["loss_recons"].item()) < 5e-3 and rel(lf[1].item(), rec["loss_vq"].item()) < 5e-3
+    fc = {}
+    for k, p in mf.named_parameters():
+        if not is_noise_bias(k) and rec["grads"][k].norm() > 1e-6:
+            g_, r_ = p.grad.double().cpu().flatten(), rec["grads"][k].double().flatten()
+            fc[k] = (float(torch.dot(g_, r_) / (g_.norm() * r_.norm())), float((g_ - r_).norm() / r_.norm()))
+    print("bf16 mode on the oracle's codes, (cosine, relative L2) vs fp32:", {k: (round(a, 4), round(b, 4)) for k, (a, b) in fc.items()})
+    big = dim >= 128 and B * T >= 2048            # the BASELINE widths; the small shapes average the bf16 noise over fewer pixels
+    dec_min = min(a for k, (a, _) in fc.items() if k.startswith("decoder."))
+    enc_min = min(a for k, (a, _) in fc.items() if k.startswith("encoder."))
+    assert dec_min > (0.99 if big else 0.97), fc
+    assert enc_min > (0.975 if big else 0.93), fc
+    assert fc["codebook.embedding.weight"][1] < 1e-2
     # autograd path in the same mode gives the same losses
     m2 = M.VQVAE(1, dim, z_dim, compute_dtype=torch.bfloat16)
     m2.load_state_dict(st0)
@@ -874,3 +962,42 @@ def test_bf16_mode_is_deterministic_and_stable_over_many_steps():
     assert h1 == h2 and torch.equal(p1, p2)
     assert all(np.isfinite(v) for pair in h1 for v in pair)
     assert h1[-1][0] < 0.5 * h1[0][0]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_configs4_per_gpu_share_256_clips(mode):
+    """BASELINE configs[4]'s per-GPU share on one GPU: 256 clips of 80 x 1024 (N = 1 310 720 latent rows, 1.34 G-element
+    activation tensors: the 31-bit index guards and the workspace sizing at their largest planned shape).  Size-independent
+    properties: the batch [c; c] (two copies of a 128-clip batch) has the same BatchNorm statistics, losses and mean gradients
+    as c alone, and the step is bitwise reproducible."""
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    torch.manual_seed(1)
+    m0 = M.VQVAE(1, 128, 512, compute_dtype=dt)
+    st0 = {k: v.clone() for k, v in m0.state_dict().items()}
+    c = torch.rand(128, 1, 80, 1024, generator=torch.Generator().manual_seed(1234)).to(DEV)
+
+    def run(batch):
+        m = M.VQVAE(1, 128, 512, compute_dtype=dt)
+        m.load_state_dict(st0)
+        st = FusedTrainStep(m.to(DEV).train(), lr=1e-3)
+        l = st.forward_backward(batch)
+        out = ([x.item() for x in l], st.opt.flat_grad.clone(), st.last_indices.clone())
+        st.opt.step()
+        assert bool(torch.isfinite(st.opt.flat_param).all())
+        return out
+
+    torch.cuda.reset_peak_memory_stats()
+    c2 = torch.cat([c, c])
+    l2, g2, i2 = run(c2)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    l2b, g2b, i2b = run(c2)
+    assert l2 == l2b and torch.equal(g2, g2b) and torch.equal(i2, i2b), "the 256-clip step must be bitwise reproducible"
+    l1, g1, i1 = run(c)
+    print(f"256 clips/GPU, {mode}: losses {l2}, peak device memory {peak:.1f} GiB of 288; 128 clips: {l1}")
+    assert all(np.isfinite(v) for v in l2)
+    assert rel(l2[0], l1[0]) < 1e-4 and rel(l2[1], l1[1]) < 1e-4
+    flips = float((i2[: i1.numel()] != i1).float().mean()) + float((i2[i1.numel():] != i1).float().mean())
+    assert flips <= (0.0 if mode == "f32" else 2e-3), flips          # same z_e rows -> same codes (bf16: statistics sum in another order)
+    d = (g2.double() - g1.double()).norm() / g1.double().norm()
+    assert float(d) < (2e-3 if mode == "f32" else 5e-2), float(d)
+    assert peak < 200.0
