@@ -38,7 +38,7 @@ extern "C" {
 #define NSG_API
 #endif
 
-#define NSG_VERSION 100 /* 0.1.0 */
+#define NSG_VERSION 101 /* bumped on ANY change of an existing entry point's signature; _lib.py refuses a library of another version */
 
 enum {
     NSG_OK = 0,
@@ -466,6 +466,13 @@ NSG_API int nsg_adam_step(float *p, const float *g, float *m, float *v, int64_t 
  * bit for the argmin to be exact.  N, K multiples of 32, D <= 256. */
 NSG_API int nsg_debug_dot(const float *x, const float *e, int32_t N, int32_t D, int32_t K, int32_t mode, float *out,
                           void *stream);
+
+/* nsg_vq_forward with the contraction on the vector ALU (an explicit fmaf chain per (row, code)) instead of the matrix
+ * cores: same arguments, same results bit for bit -- the cross-check that the MFMA form keeps the reference's
+ * summation order (src/vector_quantization.py:12-19).  Slow; tests only. */
+NSG_API int nsg_debug_vq_forward_valu(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+                                      float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Latent prior (GatedPixelCNN over the code-index grid)              src/models.py:219-341

@@ -18,6 +18,7 @@ NSG_OUT_F32 = 8
 NSG_RELU_OUT = 16
 NSG_F32 = 0
 NSG_BF16 = 1
+NSG_VERSION = 101      # include/nsg.h NSG_VERSION this binding was written against (bumped on ANY signature change)
 
 
 class ConvDesc(Structure):
@@ -115,14 +116,67 @@ _SIGS = {
     "nsg_audio_inv_preemphasis": (None, [_P, _P, c_int32, c_int32, c_float, _P]),
     "nsg_debug_dot": (None, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
 }
-# entry points declared in include/nsg.h (nsg_debug_vq_forward_valu is a test hook outside the header)
-HEADER_SYMBOLS = [k for k in _SIGS if k != "nsg_debug_vq_forward_valu"]
+# entry points declared in include/nsg.h: exactly the product library's exports (tests/test_abi.py checks both directions)
+HEADER_SYMBOLS = list(_SIGS)
 
 _lib = None
 
 
 class NsgError(RuntimeError):
     pass
+
+
+def _bind(lib):
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int32 if res is None else res
+    if lib.nsg_version() != NSG_VERSION:
+        raise NsgError(f"the HIP library reports ABI version {lib.nsg_version()}, this package binds version {NSG_VERSION}: rebuild it "
+                       "(python -m neural_sound_generation_amd.build --force)")
+    return lib
+
+
+DIAG_LIB_PATH = os.path.join(_PKG, "libnsg_diag.so")
+# run-time switches of the DIAGNOSTICS library (never of libnsg.so): name -> argument type
+_DIAG_SWITCHES = {"nsg_debug_set_patch_gemm": c_int32, "nsg_debug_set_patch_grid": c_int32, "nsg_debug_set_wgrad_strip": c_int32,
+                  "nsg_debug_set_c1_moments": c_int32, "nsg_debug_set_wgrad_bf16_native": c_int32, "nsg_debug_set_wgrad_stagger": c_int32,
+                  "nsg_debug_set_wgrad_diag": c_int32, "nsg_debug_set_wgrad_stamp_buffer": c_void_p, "nsg_debug_set_stamp_buffer": c_void_p}
+_diag = None
+
+
+def load_diag():
+    """The diagnostics build of the same library (libnsg_diag.so: -DNSG_DIAG + diag.hip; `python -m
+    neural_sound_generation_amd.build --diag`): kernel-variant switches and cycle stamps for scripts/ and the A/B tests."""
+    global _diag
+    if _diag is None:
+        import torch  # noqa: F401
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise NsgError(f"{DIAG_LIB_PATH} is missing: python -m neural_sound_generation_amd.build --diag")
+        lib = _bind(ctypes.CDLL(DIAG_LIB_PATH))
+        for name, at in _DIAG_SWITCHES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = [at]
+            fn.restype = None
+        _diag = lib
+    return _diag
+
+
+class use_diag:
+    """with use_diag() as lib: every ops.* call inside goes to the diagnostics library (whose nsg_debug_set_* switches `lib`
+    exposes); the product library is back afterwards."""
+
+    def __enter__(self):
+        global _lib
+        load()
+        self._saved = _lib
+        _lib = load_diag()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 def load():
@@ -138,25 +192,8 @@ def load():
         raise NsgError(
             f"{LIB_PATH} is missing: build the HIP kernels first (python -m neural_sound_generation_amd.build). "
             "There is no CPU fallback for this path.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)
-        fn.argtypes = args
-        fn.restype = c_int32 if res is None else res
-    if lib.nsg_version() < 100:
-        raise NsgError("libnsg.so is older than this package")
-    # experiment switches (diagnostics): NSG_GATHER_DMA=0|1, NSG_GATHER_TILE8=0|1 select gather_gemm staging / tile variants
-    for env, sym in (("NSG_GATHER_DMA", "nsg_debug_set_gather_dma"), ("NSG_GATHER_TILE8", "nsg_debug_set_gather_tile8"),
-                     ("NSG_PATCH_GEMM", "nsg_debug_set_patch_gemm"), ("NSG_PATCH_GRID", "nsg_debug_set_patch_grid"),
-                     ("NSG_WGRAD_STRIP", "nsg_debug_set_wgrad_strip"), ("NSG_PATCH_DIRECT", "nsg_debug_set_patch_direct"),
-                     ("NSG_C1_MOMENTS", "nsg_debug_set_c1_moments")):
-        if env in os.environ:
-            fn = getattr(lib, sym)
-            fn.argtypes = [c_int32]
-            fn.restype = None
-            fn(int(os.environ[env]))
-    _lib = lib
-    return lib
+    _lib = _bind(ctypes.CDLL(LIB_PATH))
+    return _lib
 
 
 # Optional per-call census for bench.py's roofline table: when CENSUS is set (an object with begin() / end(label, start,

@@ -18,9 +18,15 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libnsg.so")
-SOURCES = ["api_common.hip", "gemm_gather.hip", "gemm_patch.hip", "gemm_wgrad.hip", "gemm_wgrad_strip.hip", "gemm_flat.hip", "vq.hip", "segsum.hip", "vq_bf16.hip", "bn.hip", "elementwise.hip", "conv_api.hip", "stencil_c1.hip", "c1_mfma.hip", "prior_ops.hip", "audio.hip", "diag.hip"]
+# The diagnostics library (scripts/ and the kernel-vs-kernel A/B tests): the same sources under -DNSG_DIAG -- run-time switches
+# between kernel variants (nsg_debug_set_*), in-kernel cycle stamps -- plus the probe kernels of diag.hip.  None of that is in
+# libnsg.so: the product library exports exactly what include/nsg.h declares.
+OBJ_DIAG = os.path.join(CSRC, "_obj_diag")
+LIB_DIAG = os.path.join(PKG, "libnsg_diag.so")
+SOURCES = ["api_common.hip", "gemm_gather.hip", "gemm_patch.hip", "gemm_wgrad.hip", "gemm_wgrad_strip.hip", "gemm_flat.hip", "vq.hip", "segsum.hip", "vq_bf16.hip", "bn.hip", "elementwise.hip", "conv_api.hip", "stencil_c1.hip", "c1_mfma.hip", "prior_ops.hip", "audio.hip"]
+DIAG_SOURCES = SOURCES + ["diag.hip"]
 # -ffp-contract=off: the bit-exact VQ path spells out every fma itself; nothing may be re-fused.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden",
+FLAGS = FLAGS_ = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 
 
@@ -38,7 +44,10 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """Build libnsg.so (diag=False) or libnsg_diag.so (diag=True); returns the library's path."""
+    OBJ, LIB, SOURCES, FLAGS = ((OBJ_DIAG, LIB_DIAG, DIAG_SOURCES, FLAGS_ + ["-DNSG_DIAG"]) if diag else
+                                (globals()["OBJ"], globals()["LIB"], globals()["SOURCES"], FLAGS_))
     os.makedirs(OBJ, exist_ok=True)
     # every header any source may include: editing one rebuilds all objects (seconds per file)
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "nsg.h")]
@@ -54,7 +63,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         s, o = job
         cmd = [cc] + FLAGS + ["-c", s, "-o", o]
         if verbose:
-            print("[nsg build]", os.path.basename(s), flush=True)
+            print("[nsg build]" + (" (diag)" if diag else ""), os.path.basename(s), flush=True)
         subprocess.check_call(cmd)
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
@@ -69,3 +78,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--diag" in sys.argv:
+        build(force="--force" in sys.argv, diag=True)

@@ -4,8 +4,10 @@
 #include "nsg_common.h"
 
 // diagnostics: when set, the next gather_gemm launches stamp their main-loop clocks into this buffer
-static unsigned long long *g_debug_stamps = nullptr;
+NSG_DIAG_SWITCH(unsigned long long *, g_debug_stamps, nullptr)     // diagnostics library only (-DNSG_DIAG)
+#ifdef NSG_DIAG
 extern "C" NSG_API void nsg_debug_set_stamp_buffer(unsigned long long *buf) { g_debug_stamps = buf; }
+#endif
 
 // stencil_c1.hip
 bool nsg_c1_stencil_supported(int C);

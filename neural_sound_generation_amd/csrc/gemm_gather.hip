@@ -33,16 +33,12 @@
 
 namespace {
 
-
-// DMA = true: the operand stages are filled by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS with no VGPR -> LDS
-// transfer, the path whose ds_write_b128 cost 31 % in scripts/lds_fed_probe.py).  A wave-instruction deposits 64 x 16 B
-// contiguously, so rows are unpadded (128 B) and both the deposit and the fragment reads are XOR-swizzled
-// (piece ^= (row >> 1) & 7; row & 1 picks the bank half) to stay conflict-free.  No fused input ReLU in this form.
-template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU, bool DMA = false>
+// (Two variants were measured slower inside the training step and removed: LDS-DMA operand staging -- buffer_load ... lds
+// into a ring of three A and two B stages -- and a 256 x 128 tile on eight waves; numbers in DESIGN.md 3.1b.)
+template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2))) void gather_gemm_kernel(const GatherGemmParams p)
 {
-    static_assert(!(DMA && RELU), "the LDS-DMA staging cannot apply a ReLU on the way");
-    constexpr int LDS_PITCH = DMA ? 32 : 36;    // floats per staged row
+    constexpr int LDS_PITCH = 36;               // floats per staged row
     constexpr int EPV = 16 / (int)sizeof(TI);   // elements per 16-byte piece: 4 (fp32) or 8 (bf16)
     constexpr int KC = 8 * EPV;                 // channels per K-chunk: 128 bytes of a row
     constexpr bool BF = sizeof(TI) == 2;
@@ -51,26 +47,22 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     TO *__restrict__ gout = reinterpret_cast<TO *>(p.out);
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int NT = 64 * WM * WN;     // threads: 4 waves (128-row tiles) or 8 waves (the 256 x 128 tile, one workgroup per CU)
+    constexpr int NT = 64 * WM * WN;     // threads: 4 waves
     constexpr int RPP = NT / 8;          // rows staged per pass of the block (8 threads per 128-byte row)
     constexpr int AJ = BM / RPP;         // 16-byte pieces per thread for A
     constexpr int BJ = BN / RPP;
     constexpr int CP = BN + 4;   // epilogue staging pitch (floats)
-    static_assert((WM * WN == 4 || WM * WN == 8) && BM % RPP == 0 && BN % RPP == 0, "4 or 8 waves per block");
+    static_assert(WM * WN == 4 && BM % RPP == 0 && BN % RPP == 0, "4 waves per block");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // register staging: [2][BM][36] + [2][BN][36].  LDS-DMA: a ring of THREE A stages (the gathered activations come from
-    // HBM / MALL: two chunks of distance) and TWO B stages (the weights are L2-resident: one chunk), 80 KiB exactly at
-    // 128 x 128, so two workgroups still share a CU.
-    constexpr int ASTAGES = DMA ? 3 : 2;
+    // register staging: [2][BM][36] + [2][BN][36]
+    constexpr int ASTAGES = 2;
     float *As = smem;                               // [ASTAGES][BM][LDS_PITCH]
     float *Bs = smem + ASTAGES * BM * LDS_PITCH;    // [2][BN][LDS_PITCH]
     // the region serves the operand stages, then the output staging tile (+ the statistics scratch): sized for the larger
     constexpr int STAGE_FLOATS = ASTAGES * BM * LDS_PITCH + 2 * BN * LDS_PITCH;
     constexpr int REGION_FLOATS = STAGE_FLOATS > BM * CP + 512 ? STAGE_FLOATS : BM * CP + 512;
-    // output row offsets [BM]: behind the region; in the DMA form inside it, behind the output tile (filled after the main loop)
-    int *rowoff = reinterpret_cast<int *>(smem + (DMA ? BM * CP : REGION_FLOATS));
-    static_assert(!DMA || (BM * CP + BM) <= STAGE_FLOATS, "the DMA ring must hold the output tile and the row offsets");
+    int *rowoff = reinterpret_cast<int *>(smem + REGION_FLOATS);     // output row offsets [BM]: behind the region
     float *Cs = smem;                         // epilogue: [BM][CP], reuses As/Bs
 
     const unsigned long long st_entry = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostics
@@ -104,9 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI *>(gin), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI *>(gw), 0, (int)p.w_bytes, 0x00020000);
     const int rsub = tid >> 3;
-    // this thread's 16-byte piece inside a chunk, in elements.  DMA: LDS position (row, tid & 7) must hold global piece
-    // (tid & 7) ^ ((row >> 1) & 7); row = rsub + RPP * j and RPP is a multiple of 16, so the swizzle is the same for every j
-    const int c4 = (DMA ? ((tid & 7) ^ ((rsub >> 1) & 7)) : (tid & 7)) * EPV;
+    const int c4 = (tid & 7) * EPV;          // this thread's 16-byte piece inside a chunk, in elements
     const int ntaps = (MODE == 0) ? p.KH * p.KW : 4;
     unsigned rbase[AJ];    // BYTE offset of (b, iy0, ix0, c4) (wraps for "negative" pixels; only used when the tap is valid)
     unsigned tapmask[AJ];  // bit kh: tap row kh lies inside the image for this row; bit 16+kw: tap column kw does
@@ -162,7 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         rowoff[t] = off;
     }
     };
-    if constexpr (!DMA) fill_rowoff();
+    fill_rowoff();
 
     // the epilogue's column group of this thread and its bias values: fetched now, the epilogue must not wait on them
     constexpr int EPO = 16 / (int)sizeof(TO);   // output elements per 16-byte store
@@ -235,46 +225,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         for (int j = 0; j < BJ; ++j) *reinterpret_cast<v4f *>(b + (rsub + RPP * j) * LDS_PITCH + (tid & 7) * 4) = rb[j];
     };
 
-    // LDS-DMA form of gload + lstore: a chunk's A rows / B rows -> an LDS stage directly.  Wave w, pass j deposits rows
-    // RPP*j + 8w .. + 7.  A and B run at different distances, so each has its own chunk state.
-    int a_c0 = 0, a_kh = 0, a_kw = 0, b_c0 = 0, b_kh = 0, b_kw = 0;
-    auto advance = [&](int &c0, int &kh, int &kw) {
-        c0 += KC;
-        const int wrap = c0 >= p.CI;
-        c0 = wrap ? 0 : c0;
-        kw += wrap;
-        const int kwlim = (MODE == 0) ? p.KW : 2;
-        const int wrap2 = kw >= kwlim;
-        kw = wrap2 ? 0 : kw;
-        kh += wrap2;
-    };
-    auto dma_a = [&](int stage) {
-        const int dy = (MODE == 0) ? a_kh : -a_kh, dx = (MODE == 0) ? a_kw : -a_kw;
-        const unsigned tap_b = (unsigned)((dy * p.IW + dx) * p.CI + a_c0) * ES;
-        const bool cok = (a_c0 + c4) < p.CI;
-        const unsigned sel = cok ? ((1u << (a_kh & 15)) | (0x10000u << (a_kw & 15))) : 0xffffffffu;
-        char *abase = reinterpret_cast<char *>(As + stage * BM * LDS_PITCH) + 8 * wave * 128;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const unsigned off = ((tapmask[j] & sel) == sel) ? rbase[j] + tap_b : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(abase + RPP * j * 128), 16, (int)off, 0, 0, 0);
-        }
-        advance(a_c0, a_kh, a_kw);
-    };
-    auto dma_b = [&](int stage) {
-        const int ws = (MODE == 0) ? b_kh * p.KW + b_kw : ((1 - py) + 2 * b_kh) * 4 + (1 - px) + 2 * b_kw;
-        const unsigned wtap_b = (unsigned)(ws * p.CO * p.CI + b_c0) * ES;
-        const unsigned cm = ((b_c0 + c4) < p.CI) ? 0xffffffffu : 0u;
-        char *bbase = reinterpret_cast<char *>(Bs + stage * BN * LDS_PITCH) + 8 * wave * 128;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const unsigned m = wmask[j] & cm;
-            const unsigned off = ((wbase[j] + wtap_b) & m) | (OOB & ~m);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(bbase + RPP * j * 128), 16, (int)off, 0, 0, 0);
-        }
-        advance(b_c0, b_kh, b_kw);
-    };
-
     v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -283,15 +233,13 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int cur, int cura = -1) {
-        if (cura < 0) cura = cur;
-        const float *a_base = As + cura * BM * LDS_PITCH + (wr * TM * 32 + l31) * LDS_PITCH + (DMA ? 0 : 4 * h);
-        const float *b_base = Bs + cur * BN * LDS_PITCH + (wc * TN * 32 + l31) * LDS_PITCH + (DMA ? 0 : 4 * h);
-        const int sw = (l31 >> 1) & 7;        // DMA layout: piece c of row r sits at position c ^ ((r >> 1) & 7); r = l31 (mod 32)
+    auto compute = [&](int cur) {
+        const float *a_base = As + cur * BM * LDS_PITCH + (wr * TM * 32 + l31) * LDS_PITCH + 4 * h;
+        const float *b_base = Bs + cur * BN * LDS_PITCH + (wc * TN * 32 + l31) * LDS_PITCH + 4 * h;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             v4f a[TM], b[TN];
-            const int kofs = DMA ? (((2 * kk + h) ^ sw) * 4) : kk * 8;
+            const int kofs = kk * 8;
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v4f *>(a_base + i * 32 * LDS_PITCH + kofs);
 #pragma unroll
@@ -322,30 +270,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     // Chunk i is computed from LDS buffer i&1 while chunk i+1 waits in registers (stored to the other buffer right
     // after the MFMAs of chunk i are issued) and chunk i+2 is in flight from memory: a 32x32x16 chunk is only ~512
     // matrix-pipe cycles, shorter than a global load, so a single register stage would stall every chunk.
-    if constexpr (DMA) {
-        // While chunk i is computed (A stage i % 3, B stage i & 1): B of chunk i+1 and A of chunk i+2 are in flight.  Issue
-        // order per iteration is B first, A second, so "all but the newest AJ deposits" = vmcnt(AJ) is exactly "chunk i+1 is
-        // complete" (the counter retires in order).  Past the end every offset is out of range: zeros into a free stage.
-        static_assert(AJ == 4, "the vmcnt immediate below is written for 4 A deposits per thread");
-        dma_a(0);
-        dma_b(0);
-        dma_a(1);
-        __builtin_amdgcn_s_waitcnt(0x0f74);       // vmcnt(4): A(0), B(0) landed; A(1) may still fly
-        __syncthreads();
-        int sa = 0;                                // i % 3
-        for (int i2 = 0; i2 + 1 < nit; ++i2) {
-            const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
-            dma_b((i2 + 1) & 1);
-            dma_a(sa2);
-            compute(i2 & 1, sa);
-            __builtin_amdgcn_s_waitcnt(0x0f74);   // chunk i+1 (A issued last iteration, B this one) is in LDS
-            __syncthreads();
-            sa = sa1;
-        }
-        compute((nit - 1) & 1, sa);
-        __syncthreads();
-        fill_rowoff();                             // (behind the output tile; synchronised with the readers by the barrier below)
-    } else {
     gload(ra0, rb0);                  // chunk 0
     if (nit > 1) gload(ra1, rb1);     // chunk 1
     lstore(0, ra0, rb0);
@@ -366,7 +290,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         lstore(1, ra1, rb1);
         __syncthreads();
         compute(1);
-    }
     }
     if (p.stamps && tid == 0) {   // diagnostics: never read by any kernel
         const int sbid = blockIdx.y * gridDim.x + blockIdx.x;
@@ -531,15 +454,14 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     }
 }
 
-template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU, bool DMA = false>
+template <typename TI, typename TO, int WM, int WN, int TM, int TN, int MODE, bool RELU>
 int launch_one(const GatherGemmParams &p, hipStream_t s)
 {
-    constexpr int LDS_PITCH = DMA ? 32 : 36;
+    constexpr int LDS_PITCH = 36;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr size_t STAGE_FLOATS = (size_t)(DMA ? 3 : 2) * BM * LDS_PITCH + (size_t)2 * BN * LDS_PITCH;
+    constexpr size_t STAGE_FLOATS = (size_t)2 * BM * LDS_PITCH + (size_t)2 * BN * LDS_PITCH;
     constexpr size_t CS_FLOATS = (size_t)BM * (BN + 4) + 512;
-    const size_t lds = DMA ? STAGE_FLOATS * sizeof(float)      // (the row offsets live inside the ring in this form)
-                           : (STAGE_FLOATS > CS_FLOATS ? STAGE_FLOATS : CS_FLOATS) * sizeof(float) + BM * sizeof(int);
+    const size_t lds = (STAGE_FLOATS > CS_FLOATS ? STAGE_FLOATS : CS_FLOATS) * sizeof(float) + BM * sizeof(int);
     const int ntn = (p.CO + BN - 1) / BN;
     const int64_t ntm = nsg_cdiv(p.M, BM);
     const int64_t gx = ntm * ntn;
@@ -547,10 +469,10 @@ int launch_one(const GatherGemmParams &p, hipStream_t s)
     dim3 grid((unsigned)gx, MODE == 0 ? 1 : 4, 1);
     static LdsOptIn once;   // > 64 KiB of dynamic LDS must be opted into once per kernel and device
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU, DMA>)}, lds, "gather_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU>)}, lds, "gather_gemm");
         if (rc != NSG_OK) return rc;
     }
-    hipLaunchKernelGGL((gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU, DMA>), grid, dim3(64 * WM * WN), lds, s, p);
+    hipLaunchKernelGGL((gather_gemm_kernel<TI, TO, WM, WN, TM, TN, MODE, RELU>), grid, dim3(64 * WM * WN), lds, s, p);
     return nsg_check_launch("gather_gemm");
 }
 
@@ -562,34 +484,9 @@ int launch_cfg(const GatherGemmParams &p, hipStream_t s)
     return relu ? launch_one<TI, TO, WM, WN, TM, TN, 1, true>(p, s) : launch_one<TI, TO, WM, WN, TM, TN, 1, false>(p, s);
 }
 
-static int g_gather_dma = 0;     // LDS-DMA operand staging (bf16 128 x 128, no fused input ReLU): off, see launch_typed
-static int g_gather_tile8 = 0;   // off: faster in isolation on random data, slower inside the training step (see launch_typed)
-
 template <typename TI, typename TO>
 int launch_typed(const GatherGemmParams &p, hipStream_t s)
 {
-    if constexpr (sizeof(TI) == 2) {
-        // bf16: 256 x 128 tile on EIGHT waves (64 x 64 per wave as below, still two waves per SIMD, one workgroup per CU): the
-        // weight tile is staged once for twice the rows, 6 LDS stores per thread per chunk instead of 8.  The LDS-only
-        // probe (scripts/lds_fed_probe.py) puts this layout's ceiling at 1.28 PFLOP/s against 1.07 for two 128 x 128
-        // workgroups; a 4-wave 256 x 128 tile (128 x 64 per wave, ONE wave per SIMD) measured slower than either.
-        // Measured: in isolation on random data (scripts/ab_gather_tile8.py) +21 % on the 4x4/2 conv, +4..6 % on 3x3, -20 % on the
-        // memory-bound 1x1, -10 % on the transposed classes; but INSIDE the training step (scripts/ab_step_tile8.py, the sparse
-        // post-ReLU operands and back-to-back launches of the real thing) 601 vs 639 TFLOP/s over the step's launches at 64
-        // clips, 617 vs 640 at 128.  Kept behind nsg_debug_set_gather_tile8, default off.
-        if (g_gather_tile8 && p.mode == 0 && p.KH * p.KW * p.CI >= 1024 && p.CO > 64 && p.stats == nullptr && p.M >= 256 * 256)
-            return launch_cfg<TI, TO, 4, 2, 2, 2>(p, s);
-    }
-    if constexpr (sizeof(TI) == 2) {
-        // LDS-DMA staging (A ring of 3, B ring of 2).  Measured: run back to back on its own (sustained power, lower clock) it
-        // beats the register-staged kernel (3x3 134 vs 152 us, 4x4/2 239 vs 291 us: scripts/ab_gather_dma.py), but inside the
-        // training step, where GEMMs alternate with memory-bound kernels and the clock recovers, the register-staged kernel runs
-        // the same launches in 130 / 217 us against 135 / 228 us (NSG_GATHER_DMA=0|1 under rocprofv3).  Default off.
-        if (g_gather_dma && p.CO > 64 && !(p.flags & NSG_RELU_IN) && p.stats == nullptr) {
-            if (p.mode == 0) return launch_one<TI, TO, 2, 2, 2, 2, 0, false, true>(p, s);
-            return launch_one<TI, TO, 2, 2, 2, 2, 1, false, true>(p, s);
-        }
-    }
     if (p.CO > 64) return launch_cfg<TI, TO, 2, 2, 2, 2>(p, s);   // 128 x 128
     if (p.CO > 32) return launch_cfg<TI, TO, 2, 2, 2, 1>(p, s);   // 128 x 64
     return launch_cfg<TI, TO, 4, 1, 1, 1>(p, s);                  // 128 x 32
@@ -597,15 +494,8 @@ int launch_typed(const GatherGemmParams &p, hipStream_t s)
 
 }  // namespace
 
-extern "C" NSG_API void nsg_debug_set_gather_tile8(int on) { g_gather_tile8 = on; }
-extern "C" NSG_API void nsg_debug_set_gather_dma(int on) { g_gather_dma = on; }
-
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 {
-    GatherGemmParams q = p;         // (the byte sizes only matter to the launch itself)
-    if (!q.stats) q.stats = reinterpret_cast<float *>(16);
-    const int rec = nsg_patch_gemm_stat_records(q);
-    if (rec > 0) return rec;        // gemm_patch.hip: one record per workgroup
     return (int)nsg_cdiv(p.M, 128) * (p.mode == 0 ? 1 : 4);
 }
 

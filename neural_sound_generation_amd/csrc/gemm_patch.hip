@@ -28,9 +28,13 @@
 
 namespace {
 
-int g_patch_gemm = 1;        // nsg_debug_set_patch_gemm: 0 sends everything back to gemm_gather.hip's kernel (A/B runs)
-int g_patch_direct = 0;      // nsg_debug_set_patch_direct: the plain variant's epilogue straight from the accumulators (no LDS, no barrier).  Measured in the step: 3x3 forward 188-189 us vs 181-182 staged, transposed 405-408 vs 390-395: off
-int g_patch_grid_cap = 512;  // nsg_debug_set_patch_grid: workgroups per launch (2 per CU resident: each walks tiles with a grid stride); 0 = one tile each
+// Diagnostics builds only (libnsg_diag.so, -DNSG_DIAG): run-time switches for A/B runs.  The product library has constants here.
+NSG_DIAG_SWITCH(int, g_patch_gemm, 1)        // nsg_debug_set_patch_gemm: 0 sends everything back to gemm_gather.hip's kernel
+NSG_DIAG_SWITCH(int, g_patch_grid_cap, 512)  // nsg_debug_set_patch_grid: workgroups per launch (2 per CU resident: each walks tiles with a grid stride); 0 = one tile each
+
+#ifndef NSG_PATCH_DEEP
+#define NSG_PATCH_DEEP 1
+#endif
 
 inline int patch_grid(int ntiles) { return (g_patch_grid_cap > 0 && ntiles > g_patch_grid_cap) ? g_patch_grid_cap : ntiles; }
 
@@ -65,22 +69,17 @@ struct PatchGemmParams {
     int flags;
     unsigned in_bytes, w_bytes;
     unsigned long long *stamps;     // diagnostics build only: [workgroup][8] cycle counts (never read by any kernel)
-    float *stats;                   // STATS builds: [gridDim.x][3][CO] (count, sum, M2 about the record's mean) of the stored output
     PatchJob jobs[PG_MAX_JOBS];
     PatchTap taps[PG_MAX_TAPS];
 };
 
 // PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4); ADD / MASK: the fused epilogue operands are
 // compile-time (a run-time "maybe a load" makes hipcc guard every reuse of the destination registers with a conservative
-// vmcnt that also waits for the tile's own STORES -- the epilogue then runs at store-acknowledge latency); STAMP: diagnostics
-// M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same FLOP per cycle; the chip holds a higher clock on it)
-// STATS: the batch statistics of the BatchNorm that follows, from the store phase (one record per workgroup: a thread keeps
-// the same 8 channels for every piece it stores, so it carries their running sums across its tiles) instead of a pass over y
-// DIRECT (plain variant, 32x32x16 only): the epilogue goes straight from the accumulators to memory -- one v_permlane32_swap
-// per register gives a lane 8 consecutive channels of its pixel (16-byte stores in 32-byte segments; L2 merges the four waves'
-// quarters of a pixel row) -- no LDS staging, no barrier.  With fused operands their loads would be 32-byte segments too
-// (the vector L1's line rate again), so those variants keep the staged form.
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false, bool STATS = false, bool DIRECT = false>
+// vmcnt that also waits for the tile's own STORES -- the epilogue then runs at store-acknowledge latency); STAMP: diagnostics.
+// DEEP: the pixel fragments are fetched TWO k-steps ahead of their MFMAs (8 fragment registers per k-step pair instead of 4):
+// a wave whose SIMD partner is in its epilogue or at a barrier then still covers the LDS latency on its own (one k-step is
+// 4 MFMAs = 128 cycles when the wave has the matrix pipe to itself, less than a loaded ds_read_b128 takes to return).
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
@@ -134,24 +133,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     // A operand of the MFMA = weights, read from the fragment-ordered image: (tap, chunk) block -> this wave's 32-channel
     // block -> four 1 KiB fragments -> lane: 16 bytes each, so one wave-wide load is 1 KiB contiguous.  (From the plain
     // [tap][co][ci] image the same load touches 32 cache lines for 32 bytes each and the step ran at the vector L1's line
-    // rate: SQ counters, DESIGN.md.)  32x32x16: fragment kk, lane (r = x31, h) = w[co = 32 w + r][ci = 16 kk + 8 h .. + 7];
-    // 16x16x32: fragment 2 cb + ks, lane (i = lane & 15, kq = lane >> 4) = w[co = 32 w + 16 cb + i][ci = 32 ks + 8 kq .. + 7].
+    // rate: SQ counters, DESIGN.md.)  Fragment kk, lane (r = x31, h) = w[co = 32 w + r][ci = 16 kk + 8 h .. + 7].
     const unsigned wlane = (unsigned)((((n0 >> 5) + wave) * 4 * 64 + lane) * 16);
-    // B operand = pixels.  32x32x16: lane (x31, h) of tile row y reads slot (y PW + x31) + delta, piece 2 kk + h;
-    // 16x16x32: lane (px = lane & 15, kq) of block (y, xh) reads slot (y PW + 16 xh + px) + delta, piece 4 ks + kq.
+    // B operand = pixels: lane (x31, h) of tile row y reads slot (y PW + x31) + delta, piece 2 kk + h.
     unsigned arow[4];
 #pragma unroll
-    for (int y = 0; y < 4; ++y)
-        arow[y] = M16 ? (unsigned)((y * PW + (lane & 15)) * 16 + (lane >> 4) * PLANE) : (unsigned)((y * PW + x31) * 16 + h * PLANE);
+    for (int y = 0; y < 4; ++y) arow[y] = (unsigned)((y * PW + x31) * 16 + h * PLANE);
 
     const int cg = tid & 15;                 // epilogue: this thread's 8-channel group and its bias
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
-    float st_sum[STATS ? 8 : 1], st_sq[STATS ? 8 : 1], st_pv[STATS ? 8 : 1], st_cnt = 0.f;   // sums of (y - pivot), (y - pivot)^2, the pivot (the thread's first value), the count
-#pragma unroll
-    for (int e = 0; e < (STATS ? 8 : 1); ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; st_pv[e] = 0.f; }
 
     // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
     // would share lgkmcnt with the fragment reads and drain them.
@@ -171,10 +164,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         return PatchJob{c0, (short)(jj & 0xffff), (short)(jj >> 16), (short)(oo & 0xff), (short)((oo >> 8) & 0xff), (oo >> 16) & 1};
     };
 
-    v16f acc[4];             // 32x32x16: one 32 x 32 tile per tile row.  16x16x32: the same 64 registers as 16 tiles of
-                             // 16 x 16: registers 4 (4 xh + 2 cb ... ) -- see acc16()
+    v16f acc[4];             // one 32 x 32 tile (32 channels x 32 pixels) per tile row
     v4f breg[2][4];          // weight fragments of two taps
-    v4f afr[M16 ? 8 : 4];    // pixel fragments of one k-step: each is re-read for the next k-step right after its last MFMA
+    v4f afr[DEEP ? 2 : 1][4];    // pixel fragments of one k-step (DEEP: two): each is re-read for a later k-step right after its MFMA
     v4f ptmp[2][PPT];        // patch pieces in flight: fetched in tap t (even / odd half), written to LDS in tap t + 2
 
     // ---- job stream: (tile, job) for this workgroup, tiles bid, bid + grid, ... ----
@@ -237,65 +229,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         for (int kk = 0; kk < 4; ++kk)
             bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 1024 * kk), so, 0));
     };
-    auto read_a1 = [&](int y, int buf, int q, int kk) {
-        afr[y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 2 * kk * PLANE + arow[y]);
-    };
-    auto read_a16 = [&](int y, int xh, int buf, int q, int ks) {
-        afr[2 * y + xh] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 4 * ks * PLANE + 256 * xh + arow[y]);
+    auto read_a = [&](int st, int y, int buf, int q, int kk) {
+        afr[st][y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 2 * kk * PLANE + arow[y]);
     };
     auto read_a_first = [&](int buf, int q) {
-        if constexpr (M16) {
 #pragma unroll
-            for (int y = 0; y < 4; ++y) { read_a16(y, 0, buf, q, 0); read_a16(y, 1, buf, q, 0); }
-        } else {
+        for (int y = 0; y < 4; ++y) read_a(0, y, buf, q, 0);
+        if constexpr (DEEP) {
 #pragma unroll
-            for (int y = 0; y < 4; ++y) read_a1(y, buf, q, 0);
+            for (int y = 0; y < 4; ++y) read_a(1, y, buf, q, 1);
         }
     };
-    // One tap.  On entry afr holds the first k-step of tap q; on exit the first k-step of tap qn.  At the end of a job qn = q:
-    // the next patch is not visible before the job-boundary barrier, so the read is a dummy (branch-free) and run_job reads
-    // the real fragments after the barrier.
+    // One tap.  On entry afr holds the first k-step (DEEP: the first two) of tap q; on exit of tap qn.  At the end of a job
+    // qn = q: the next patch is not visible before the job-boundary barrier, so the reads are dummies (branch-free) and
+    // run_job reads the real fragments after the barrier.
     auto mfma_chain = [&](const v4f (&bq)[4], int buf, int q, int qn) __attribute__((always_inline)) {
-        if constexpr (M16) {
-            // accumulator of block (y, xh, cb): four floats = registers 4 (2 xh + cb) .. + 3 of acc[y]
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+        for (int kk = 0; kk < 4; ++kk) {
+            constexpr int AHEAD = DEEP ? 2 : 1;
+            const int st = DEEP ? (kk & 1) : 0;
 #pragma unroll
-                for (int y = 0; y < 4; ++y)
-#pragma unroll
-                    for (int xh = 0; xh < 2; ++xh) {
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb) {
-                            const int o = 4 * (2 * xh + cb);
-                            v4f c4 = {acc[y][o], acc[y][o + 1], acc[y][o + 2], acc[y][o + 3]};
-                            c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[2 * cb + ks]),
-                                                                         __builtin_bit_cast(bf16x8, afr[2 * y + xh]), c4, 0, 0, 0);
-                            acc[y][o] = c4.x; acc[y][o + 1] = c4.y; acc[y][o + 2] = c4.z; acc[y][o + 3] = c4.w;
-                        }
-                        if (ks == 0) read_a16(y, xh, buf, q, 1);
-                        else read_a16(y, xh, buf, qn, 0);
-                    }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+            for (int y = 0; y < 4; ++y) {
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[st][y]), acc[y], 0, 0, 0);
+                if (kk + AHEAD < 4) read_a(st, y, buf, q, kk + AHEAD);
+                else read_a(st, y, buf, qn, kk + AHEAD - 4);
             }
-        } else {
+            // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next 3 / 7 MFMAs)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[y]), acc[y], 0, 0, 0);
-                    if (kk < 3) read_a1(y, buf, q, kk + 1);
-                    else read_a1(y, buf, qn, 0);
-                }
-                // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next three MFMAs)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+            for (int y = 0; y < 4; ++y) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
     };
@@ -326,43 +289,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     auto flush = [&](int tile, const PatchJob &jb, int buf) __attribute__((always_inline)) {
         int b, ty, tx;
         tile_origin(tile, b, ty, tx);
-        if constexpr (DIRECT) {
-            static_assert(!DIRECT || (!ADD && !MASK && !M16 && !STATS), "the register epilogue is the plain 32x32x16 variant's");
-            // register group g of lane (x, h) of tile row y = channels 32 w + 8 g + 4 h .. + 3 of pixel (y, x); swapping the upper
-            // half of group g with the lower half of group g + 1 leaves lane (x, 0) with channels 8 g .. + 7 and lane (x, 1)
-            // with 8 (g + 1) .. + 7: 16 bytes of bf16 each.  Same arithmetic and order as the staged form.
-            float bvd[2][8];
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bvd[gp][e] = p.bias ? p.bias[n0 + 32 * wave + 16 * gp + 8 * h + e] : 0.f;
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                const int oy = (ty * 4 + y) * p.os + jb.oy;
-                const int ox = (tx * 32 + x31) * p.os + jb.ox;
-                const unsigned pix = (oy < p.OH && ox < p.OW) ? (unsigned)(((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + 32 * wave + 8 * h) * 2u : OOB;
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(nsg_fbits(acc[y][8 * gp + i]), nsg_fbits(acc[y][8 * gp + 4 + i]), false, false);
-                        v[i] = nsg_bitsf(sw[0]);
-                        v[4 + i] = nsg_bitsf(sw[1]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bvd[gp][e];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];
-                    unsigned u[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
-                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                    __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)(pix == OOB ? OOB : pix + 32u * gp), 0, 0);
-                }
-            }
-            return;
-        }
         float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
         // this thread's 8 output pieces: tile row y, pixel (tid >> 4) + 16 e2, channels 8 cg .. + 7
         unsigned off[4][2];     // BYTE offsets; OOB for pixels outside the image
@@ -392,10 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             // this wave's 32 pixels x 32 channels of tile row y: register group g of lane (x, h) = channels 32 w + 8 g + 4 h .. + 3
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // 32x32x16: group g of lane (x, h) = channels 8 g + 4 h .. + 3 of pixel x; 16x16x32: group g = 2 xh + cb of lane
-                // (px, kq) = channels 16 cb + 4 kq .. + 3 of pixel 16 xh + px
-                float *dst = M16 ? Cs + (16 * (g >> 1) + (lane & 15)) * CPITCH + 32 * wave + 16 * (g & 1) + 4 * (lane >> 4)
-                                 : Cs + x31 * CPITCH + 32 * wave + 8 * g + 4 * h;
+                float *dst = Cs + x31 * CPITCH + 32 * wave + 8 * g + 4 * h;
                 *reinterpret_cast<v4f *>(dst) = v4f{acc[y][4 * g], acc[y][4 * g + 1], acc[y][4 * g + 2], acc[y][4 * g + 3]};
             }
             __syncthreads();
@@ -424,21 +347,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
                 unsigned u[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
-                if constexpr (STATS) {      // one pass about a pivot, of the values AS STORED (rounded to bf16), real pixels only
-                    const float live = off[y][e2] != OOB ? 1.f : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float y0 = nsg_bitsf(u[i] << 16), y1 = nsg_bitsf(u[i] & 0xffff0000u);
-                        st_pv[2 * i] = (st_cnt == 0.f) ? y0 : st_pv[2 * i];
-                        st_pv[2 * i + 1] = (st_cnt == 0.f) ? y1 : st_pv[2 * i + 1];
-                        const float d0 = (y0 - st_pv[2 * i]) * live, d1 = (y1 - st_pv[2 * i + 1]) * live;
-                        st_sum[2 * i] += d0;
-                        st_sum[2 * i + 1] += d1;
-                        st_sq[2 * i] = __builtin_fmaf(d0, d0, st_sq[2 * i]);
-                        st_sq[2 * i + 1] = __builtin_fmaf(d1, d1, st_sq[2 * i + 1]);
-                    }
-                    st_cnt += live;
-                }
                 typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)off[y][e2], 0, 0);
             }
@@ -506,39 +414,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             do_job(std::integral_constant<int, 1>{});
         }
     }
-    if constexpr (STATS) {
-        // (count, mean, M2) of each thread, pooled over the 16 threads of its channel group in thread order (double): one record
-        __syncthreads();
-        float *red = reinterpret_cast<float *>(smem);      // [17][256]: 8 means, 8 M2s, the count
-        const float inv = st_cnt > 0.f ? 1.f / st_cnt : 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[e * 256 + tid] = st_pv[e] + st_sum[e] * inv;
-            red[(8 + e) * 256 + tid] = fmaxf(st_sq[e] - st_sum[e] * st_sum[e] * inv, 0.f);
-        }
-        red[16 * 256 + tid] = st_cnt;
-        __syncthreads();
-        if (tid < 128) {
-            const int grp = tid >> 3, e = tid & 7;
-            double N = 0.0, S = 0.0;
-            for (int r = 0; r < 16; ++r) {
-                const double n = red[16 * 256 + r * 16 + grp];
-                N += n;
-                S += n * (double)red[e * 256 + r * 16 + grp];
-            }
-            const double mu = N > 0.0 ? S / N : 0.0;
-            double Q = 0.0;
-            for (int r = 0; r < 16; ++r) {
-                const double n = red[16 * 256 + r * 16 + grp];
-                const double dl = (double)red[e * 256 + r * 16 + grp] - mu;
-                Q += n > 0.0 ? (double)red[(8 + e) * 256 + r * 16 + grp] + n * dl * dl : 0.0;
-            }
-            float *dst = p.stats + (size_t)blockIdx.x * 3 * p.CO + n0 + tid;
-            dst[0] = (float)N;
-            dst[p.CO] = (float)S;
-            dst[2 * p.CO] = (float)Q;
-        }
-    }
     if constexpr (STAMP) {
         if (tid == 0 && p.stamps) {
             unsigned long long *o = p.stamps + 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
@@ -548,7 +423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
 }
 
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool M16, bool STAMP = false, bool STATS = false, bool DIRECT = false>
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP>
 int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
@@ -556,35 +431,30 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
     const size_t lds = 2 * BUF_BYTES;
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP, STATS, DIRECT>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
     const int gx = patch_grid(p.ntiles);
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, M16, STAMP, STATS, DIRECT>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }
 
-template <int PH, int PW, int NT, bool M16, bool STAMP>
+template <int PH, int PW, int NT, bool STAMP>
 int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
-    if constexpr (!STAMP) {
-        if (p.stats) return launch_patch<PH, PW, NT, false, false, M16, false, true>(p, ntiles_n, s);
-    }
-    if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, M16, STAMP>(p, ntiles_n, s);
-    if (p.epi_add) return launch_patch<PH, PW, NT, true, false, M16, STAMP>(p, ntiles_n, s);
-    if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, M16, STAMP>(p, ntiles_n, s);
-    if constexpr (!M16) {
-        if (g_patch_direct) return launch_patch<PH, PW, NT, false, false, M16, STAMP, false, true>(p, ntiles_n, s);
-    }
-    return launch_patch<PH, PW, NT, false, false, M16, STAMP>(p, ntiles_n, s);
+    if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, STAMP>(p, ntiles_n, s);
+    if (p.epi_add) return launch_patch<PH, PW, NT, true, false, STAMP>(p, ntiles_n, s);
+    if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, STAMP>(p, ntiles_n, s);
+    return launch_patch<PH, PW, NT, false, false, STAMP>(p, ntiles_n, s);
 }
 
 }  // namespace
 
+#ifdef NSG_DIAG
 extern "C" NSG_API void nsg_debug_set_patch_gemm(int on) { g_patch_gemm = on; }
 extern "C" NSG_API void nsg_debug_set_patch_grid(int cap) { g_patch_grid_cap = cap; }
-extern "C" NSG_API void nsg_debug_set_patch_direct(int on) { g_patch_direct = on; }
+#endif
 
 // kind of the launch for this file (0: 3x3 stride 1, 1: 4x4 stride 2 pad 1, 2: transposed 4/2/1), or -1: not taken
 static int patch_kind(const GatherGemmParams &g)
@@ -592,7 +462,7 @@ static int patch_kind(const GatherGemmParams &g)
     if (!g_patch_gemm) return -1;
     if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return -1;
     if (g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) return -1;
-    if (g.stats && (g.epi_add || g.epi_mask || (g.flags & NSG_RELU_OUT) || g.stamps)) return -1;
+    if (g.stats) return -1;      // BatchNorm statistics from the store phase: gemm_gather.hip's epilogue has that form
     if (g.CI % 64 != 0 || g.CO % 128 != 0) return -1;
     const int chunks = g.CI / 64;
     int kind;
@@ -605,13 +475,6 @@ static int patch_kind(const GatherGemmParams &g)
     if (njobs > PG_MAX_JOBS || njobs * ntaps > PG_MAX_TAPS) return -1;
     if ((int64_t)g.B * nsg_cdiv(g.RH, 4) * nsg_cdiv(g.RW, 32) > 0x3fffffff) return -1;
     return kind;
-}
-
-// Statistics records a launch with these parameters writes when gemm_patch.hip runs it (one per workgroup), or 0 when it does not.
-int nsg_patch_gemm_stat_records(const GatherGemmParams &g)
-{
-    if (patch_kind(g) < 0) return 0;
-    return patch_grid((int)((int64_t)g.B * nsg_cdiv(g.RH, 4) * nsg_cdiv(g.RW, 32)));
 }
 
 // Runs the launch on the patch-staged kernel when its shape is one this file implements; *handled says whether it did.
@@ -647,7 +510,6 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     p.flags = g.flags;
     p.in_bytes = g.in_bytes; p.w_bytes = g.w_bytes;
     p.stamps = g.stamps;
-    p.stats = g.stats;
     const int64_t blk = (int64_t)(g.CO / 32) * 4096;    // bytes of one (tap, 64-channel chunk) block of the fragment-ordered image
     auto wblock = [&](int ws, int c) { return (unsigned)(((int64_t)ws * chunks + c) * blk); };
     int j = 0;
@@ -682,10 +544,12 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     }
     *handled = true;
     const int ntn = g.CO / 128;
+#ifdef NSG_DIAG
     if (g.stamps) {     // diagnostics build of the same kernel (scripts/patch_gemm_shares.py)
-        if (kind == 0) return launch_patch_epi<6, 34, 9, NSG_FRAG_M16 != 0, true>(p, ntn, s);
-        return launch_patch_epi<5, 33, 4, NSG_FRAG_M16 != 0, true>(p, ntn, s);
+        if (kind == 0) return launch_patch_epi<6, 34, 9, true>(p, ntn, s);
+        return launch_patch_epi<5, 33, 4, true>(p, ntn, s);
     }
-    if (kind == 0) return launch_patch_epi<6, 34, 9, NSG_FRAG_M16 != 0, false>(p, ntn, s);
-    return launch_patch_epi<5, 33, 4, NSG_FRAG_M16 != 0, false>(p, ntn, s);
+#endif
+    if (kind == 0) return launch_patch_epi<6, 34, 9, false>(p, ntn, s);
+    return launch_patch_epi<5, 33, 4, false>(p, ntn, s);
 }

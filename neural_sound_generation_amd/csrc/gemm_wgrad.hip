@@ -16,14 +16,17 @@
 #include "nsg_common.h"
 #include <type_traits>
 
-static unsigned long long *g_wgrad_stamps = nullptr;   // diagnostics
+// Diagnostics library only (-DNSG_DIAG): run-time switches; constants in libnsg.so
+NSG_DIAG_SWITCH(unsigned long long *, g_wgrad_stamps, nullptr)
+NSG_DIAG_SWITCH(int, g_wgrad_stagger, 0)
+NSG_DIAG_SWITCH(int, g_wgrad_bf16_native, 1)   // 0: widen bf16 operands to fp32 at staging and use the fp32 MFMA (cross-check path)
+#ifdef NSG_DIAG
 static int g_wgrad_diag = 0;
-static int g_wgrad_stagger = 0;
-static int g_wgrad_bf16_native = 1;   // 0: widen bf16 operands to fp32 at staging and use the fp32 MFMA (cross-check path)
 extern "C" NSG_API void nsg_debug_set_wgrad_bf16_native(int on) { g_wgrad_bf16_native = on; }
 extern "C" NSG_API void nsg_debug_set_wgrad_stagger(int units) { g_wgrad_stagger = units; }
 extern "C" NSG_API void nsg_debug_set_wgrad_diag(int on) { g_wgrad_diag = on; }
 extern "C" NSG_API void nsg_debug_set_wgrad_stamp_buffer(unsigned long long *buf) { g_wgrad_stamps = buf; }
+#endif
 
 namespace {
 
@@ -861,8 +864,10 @@ int nsg_launch_wgrad(WgradParams p, float *dst, void *ws, size_t ws_bytes, hipSt
         rc = launch_wg<4, 1, 1, 1>(p, sp.nslab, s);          // 128 x 32 (im2col'd single-channel layers)
     } else if (p.A <= 64 && p.C <= 64) {
         rc = launch_wg<2, 2, 1, 1>(p, sp.nslab, s);          // 64 x 64
+#ifdef NSG_DIAG
     } else if (g_wgrad_diag && p.stamps && !p.onehot) {
         rc = launch_wg_diag<2, 2, 2, 2>(p, sp.nslab, s);     // diagnostics build of the 128 x 128 kernel
+#endif
     } else {
         rc = launch_wg<2, 2, 2, 2>(p, sp.nslab, s);          // 128 x 128
     }

@@ -19,7 +19,7 @@
 
 namespace {
 
-int g_wgrad_strip = 3;    // nsg_debug_set_wgrad_strip: bit 0 = the bf16 form, bit 1 = the fp32 form; 0 sends everything back to gemm_wgrad.hip's per-tap kernels (A/B runs)
+NSG_DIAG_SWITCH(int, g_wgrad_strip, 3)    // nsg_debug_set_wgrad_strip (diagnostics library only): bit 0 = the bf16 form, bit 1 = the fp32 form; 0 sends everything back to gemm_wgrad.hip's per-tap kernels (A/B runs)
 
 constexpr int SP = 64;              // pixels per strip chunk (4 MFMA k-steps of 16)
 constexpr int PITCH = 128 + 32;     // LDS row pitch in bf16 elements: 2 * 128 + 64 bytes (conflict-free transposing reads)
@@ -398,7 +398,9 @@ int launch_strip(const StripParams &p, int nslab, hipStream_t s)
 
 }  // namespace
 
+#ifdef NSG_DIAG
 extern "C" NSG_API void nsg_debug_set_wgrad_strip(int on) { g_wgrad_strip = on; }
+#endif
 
 // slabs of the strip kernel for a layer with `ntaps` taps: one resident round of the 256 CUs (one workgroup each)
 int nsg_wgrad_strip_slabs(int ntaps, int A, int C)

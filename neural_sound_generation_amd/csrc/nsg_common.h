@@ -118,6 +118,15 @@ struct LdsOptIn {
 };
 int nsg_lds_opt_in(LdsOptIn &once, std::initializer_list<const void *> kernels, size_t lds_bytes, const char *what);
 
+// Run-time switches between kernel variants exist only in the diagnostics library (libnsg_diag.so, built with -DNSG_DIAG for
+// scripts/ and the A/B tests): there they are file-static ints behind nsg_debug_set_* entry points; in libnsg.so they are
+// compile-time constants (no mutable global state, no undeclared exports).
+#ifdef NSG_DIAG
+#define NSG_DIAG_SWITCH(type, name, init) static type name = init;
+#else
+#define NSG_DIAG_SWITCH(type, name, init) static constexpr type name = init;
+#endif
+
 static inline bool nsg_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ bool nsg_aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int64_t nsg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -206,26 +215,18 @@ struct WgradParams {
 
 // A packed bf16 weight image [taps][NN][CC] is followed by its fragment-ordered twin (conv_api.hip: PackJob::frag) when:
 static inline bool nsg_frag_image(int NN, int CC) { return NN % 128 == 0 && CC % 64 == 0; }
-// Order of that twin = the MFMA shape gemm_patch.hip is built for (one build-time choice shared with conv_api.hip's pack kernel):
-//   0: v_mfma_f32_32x32x16_bf16  [t][c/64][n/32][(c%64)/16][lane = n%32 + 32*((c%16)/8)][c%8]
-//   1: v_mfma_f32_16x16x32_bf16  [t][c/64][n/32][(n%32)/16][(c%64)/32][lane = n%16 + 16*((c%32)/8)][c%8]
-#ifndef NSG_FRAG_M16
-#define NSG_FRAG_M16 0   /* measured in the step (B = 128, D = 128): 946 TF (32x32x16) vs 955-961 TF (16x16x32): within noise -- not MFMA-clock-bound */
-#endif
+// Order of that twin = v_mfma_f32_32x32x16_bf16's operand fragments as gemm_patch.hip's waves load them:
+//   [t][c/64][n/32][(c%64)/16][lane = n%32 + 32*((c%16)/8)][c%8]
+// (a v_mfma_f32_16x16x32_bf16 order was measured at parity inside the step, 955-961 vs 946 TF, and removed)
 __host__ __device__ static inline int64_t nsg_frag_index(int t, int n, int c, int NN, int CC)
 {
     const int64_t blk = ((int64_t)(t * (CC >> 6) + (c >> 6)) * (NN >> 5) + (n >> 5)) * 4;
-#if NSG_FRAG_M16
-    return ((blk + 2 * ((n & 31) >> 4) + ((c & 63) >> 5)) * 64 + (n & 15) + 16 * ((c & 31) >> 3)) * 8 + (c & 7);
-#else
     return ((blk + ((c & 63) >> 4)) * 64 + (n & 31) + 32 * ((c & 15) >> 3)) * 8 + (c & 7);
-#endif
 }
 int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
 // gemm_patch.hip: the patch-staged bf16 kernel for the shapes it implements (3x3/1, 4x4/2 and the transposed 4/2/1 with
 // C_in % 64 == 0, C_out % 128 == 0, bf16 in and out); p must have in_bytes / w_bytes filled in.  *handled = false -> not run.
 int nsg_launch_patch_gemm(const GatherGemmParams &p, hipStream_t s, bool *handled);
-int nsg_patch_gemm_stat_records(const GatherGemmParams &p);     // statistics records (p.stats) such a launch writes; 0: not taken
 // Returns bytes of partial-slab workspace it will use for these sizes.
 size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C);
 // dst[(a*C + c)*ntaps + t] = sum over slabs (fixed order) of partial; dst fully overwritten.

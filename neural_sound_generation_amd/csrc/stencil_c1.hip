@@ -664,8 +664,10 @@ int nsg_launch_c1m_bwd_onepass(const float *img, const float *w, const float *bi
 int nsg_launch_c1m_onepass_fixup(const double *mom, const float *w, const float *bias, const float *mean, const float *invstd,
                                  const float *gamma, const float *dgamma, const float *dbeta, int64_t M, int C, float *dw, float *dbias,
                                  hipStream_t s);
-int g_c1_moments = 1;     // nsg_debug_set_c1_moments: 0 = the two-pass forms (statistics pass over h; sums pass + gradient pass over dy)
+NSG_DIAG_SWITCH(int, g_c1_moments, 1)     // nsg_debug_set_c1_moments (diagnostics library only): 0 = the two-pass forms (statistics pass over h; sums pass + gradient pass over dy)
+#ifdef NSG_DIAG
 extern "C" NSG_API void nsg_debug_set_c1_moments(int on) { g_c1_moments = on; }
+#endif
 
 namespace {
 constexpr int FUSED_BLOCKS = 1024;      // = bn.hip's MAX_SLABS (bn_bwd_final_kernel) and WGRAD_BLOCKS

@@ -424,8 +424,7 @@ int nsg_vq_forward(const float *x, const float *e, int64_t N, int32_t D, int32_t
     return vq_forward_impl(true, x, e, N, D, K, idx_out, codes_out, dmin_out, workspace, workspace_bytes, stream);
 }
 
-// not in nsg.h: the vector-ALU cross-check build of the same kernel (tests only)
-NSG_API int nsg_debug_vq_forward_valu(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
+int nsg_debug_vq_forward_valu(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out,
                                       float *codes_out, float *dmin_out, void *workspace, size_t workspace_bytes,
                                       void *stream)
 {

@@ -111,28 +111,14 @@ def _bump(bn: "BNParams"):
         ops.increment_counters([bn.num_batches_tracked])
 
 
-# The patch-staged bf16 conv kernel (gemm_patch.hip) keeps the statistics of its output as running sums of each thread's own 8
-# channels and writes ONE record per workgroup (tests/test_gpu_ops.py::test_patch_staged_conv_kernel).  Measured in the step
-# (B = 128, D = 128): the five layers' bn_stats passes (64 us each) go, but the 3x3 forward launches take 206-211 us instead
-# of 183-185 (the sums ride in the store phase, plus two finalizer launches) and the transposed conv 450 us instead of 389:
-# 9.525 vs 9.60-9.63 ms per step (-0.8 %) while the conv kernel's own roofline fraction drops 5 %.  Re-measured at the end of
-# round 2 (same box, alternating runs): 8.815 ms off, 8.715 with the transposed conv only (=2), 8.670 with all five (=1), the
-# in-region conv rate 920 / 906 / 879 TF.  Off by default: the step gains 1.7 % at most, the kernel whose roofline the
-# bench reports loses 4.5 % (NSG_PATCH_BN_STATS=1 or 2 turns it on).
 FUSED_OUT_LOSS = _os.environ.get("NSG_FUSED_OUT_LOSS", "1") == "1"  # reconstruction loss + Tanh backward in the output layer's image pass
 FUSED_1X1_BWD = _os.environ.get("NSG_FUSED_1X1_BWD", "1") == "1"    # the 1x1 conv's data and weight gradients in one kernel (C = 128)
-PATCH_BN_STATS = int(_os.environ.get("NSG_PATCH_BN_STATS", "0"))      # 1: every patch_gemm layer in front of a BatchNorm; 2: the transposed conv only
-
-
-def _patch_stats_ok(d, flags) -> bool:
-    return (PATCH_BN_STATS and (PATCH_BN_STATS == 1 or d.transposed) and d.dtype == ops.NSG_BF16 and flags == 0 and d.C_in % 64 == 0 and d.C_out % 128 == 0 and d.k_w == 0 and
-            ((d.k == 3 and d.stride == 1) or (d.k == 4 and d.stride == 2)))
 
 
 def _conv_bn(d, x, wf, conv: ConvParams, bn: BNParams, training: bool, flags=0):
     """conv (+fused input ReLU) followed by BatchNorm statistics: one fused call in training mode
     (the statistics come out of the conv epilogue), two calls in eval mode."""
-    if training and (FUSED_BN_STATS or _patch_stats_ok(d, flags)):
+    if training and FUSED_BN_STATS:
         h, mean, invstd = ops.conv_forward_bnstats(d, x, wf, conv.bias, flags=flags, running_mean=bn.running_mean,
                                                    running_var=bn.running_var)
         _bump(bn)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_sound_generation_amd import _lib
 
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()      # the diagnostics library (libnsg_diag.so: switches, stamps, probe kernels) for this whole process
 lib.nsg_debug_lds_fed_loop.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
 blocks, chunks = 2560, 18 * 8
 sink = torch.empty(blocks * 256, device="cuda:0")

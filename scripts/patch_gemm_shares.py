@@ -4,7 +4,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neural_sound_generation_amd import _lib, ops
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()      # the diagnostics library (libnsg_diag.so: switches, stamps, probe kernels) for this whole process
 lib.nsg_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 dev = "cuda:0"
 B, D = int(os.environ.get("B", "128")), int(os.environ.get("D", "128"))

@@ -2,7 +2,7 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from neural_sound_generation_amd import _lib, ops
-lib = _lib.load()
+lib = _lib.use_diag().__enter__()      # the diagnostics library (libnsg_diag.so: switches, stamps, probe kernels) for this whole process
 lib.nsg_debug_set_wgrad_stamp_buffer.argtypes = [ctypes.c_void_p]
 dev="cuda:0"; B,D=64,128
 k,s_,p_,ih,iw=3,1,1,20,256

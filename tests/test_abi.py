@@ -16,14 +16,37 @@ def header_symbols():
     return sorted(set(re.findall(r"NSG_API\s+[\w\s\*]+?\b(nsg_\w+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
+def exported_symbols(path):
+    """Dynamic symbols a shared object DEFINES (nm -D --defined-only), nsg_* only."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("nsg_")})
+
+
+def test_library_exports_exactly_the_declared_symbols():
+    """include/nsg.h IS the ABI, in both directions: every declared entry point is exported, and libnsg.so exports no nsg_*
+    symbol the header does not declare (round 2's library carried 13 undeclared nsg_debug_set_* switches over process-global
+    state; they now exist only in the diagnostics build, libnsg_diag.so)."""
     lib = _lib.load()
     declared = header_symbols()
     assert len(declared) >= 25
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/nsg.h but not exported by libnsg.so"
     assert sorted(_lib.HEADER_SYMBOLS) == declared, "the ctypes table and include/nsg.h disagree"
-    assert lib.nsg_version() == 100
+    exported = exported_symbols(_lib.LIB_PATH)
+    extra = sorted(set(exported) - set(declared))
+    assert not extra, f"libnsg.so exports symbols include/nsg.h does not declare: {extra}"
+    assert not [n for n in exported if n.startswith("nsg_debug_set")], "a run-time variant switch leaked into the product library"
+    m = re.search(r"#define\s+NSG_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "nsg.h")).read())
+    assert lib.nsg_version() == int(m.group(1)) == _lib.NSG_VERSION
+
+
+def test_diagnostics_library_is_a_superset_with_the_switches():
+    if not os.path.exists(_lib.DIAG_LIB_PATH):
+        pytest.skip("libnsg_diag.so not built (python -m neural_sound_generation_amd.build --diag)")
+    exported = set(exported_symbols(_lib.DIAG_LIB_PATH))
+    assert set(header_symbols()) <= exported
+    assert set(_lib._DIAG_SWITCHES) <= exported
 
 
 def test_invalid_arguments_are_rejected_before_any_launch():

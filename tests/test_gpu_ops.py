@@ -499,7 +499,6 @@ def test_patch_staged_conv_kernel(case):
     dyg = gpu(nhwc(dy)).to(bf)
     skip = torch.randn(B, IH, IW, Ci, generator=g).to(bf).to(DEV)
     rx = torch.relu(torch.randn(B, IH, IW, Ci, generator=g)).to(bf).to(DEV)
-    lib = _lib.load()
 
     def run():
         return (ops.conv_forward(d, xg, wf, gpu(b)), ops.conv_forward(d, xg, wf, gpu(b), flags=ops.NSG_RELU_OUT),
@@ -508,18 +507,19 @@ def test_patch_staged_conv_kernel(case):
     again = run()
     dw_new, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)      # gemm_wgrad_strip.hip when both channel counts are multiples of 128
     dw_again, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)
-    lib.nsg_debug_set_patch_gemm(0)
-    lib.nsg_debug_set_wgrad_strip(0)
-    try:
-        old = run()
-        dw_old, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)
-    finally:
-        lib.nsg_debug_set_patch_gemm(1)
-        lib.nsg_debug_set_wgrad_strip(1)
-    # BatchNorm batch statistics from the store phase (one record per workgroup) == a pass over the stored tensor
+    with _lib.use_diag() as lib:        # the diagnostics build of the same sources: switch to gemm_gather.hip / the per-tap kernels
+        lib.nsg_debug_set_patch_gemm(0)
+        lib.nsg_debug_set_wgrad_strip(0)
+        try:
+            old = run()
+            dw_old, _ = ops.conv_wgrad(d, xg, dyg, wshape, want_bias=False)
+        finally:
+            lib.nsg_debug_set_patch_gemm(1)
+            lib.nsg_debug_set_wgrad_strip(1)
+    # BatchNorm batch statistics from the conv's store phase (gemm_gather.hip's epilogue has that form) == a pass over the stored tensor
     rmg, rvg = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
     ys, mean, invstd = ops.conv_forward_bnstats(d, xg, wf, gpu(b), running_mean=rmg, running_var=rvg)
-    assert torch.equal(ys, new[0]), "the statistics variant must store the same tensor"
+    assert torch.equal(ys, old[0]), "the statistics variant must store the same tensor as the plain gather kernel"
     m2, i2 = ops.bn_stats(ys, Co)
     spread = float((1.0 / i2).max())
     np.testing.assert_allclose(mean.cpu().numpy(), m2.cpu().numpy(), rtol=1e-5, atol=2e-6 * spread + 1e-6)
@@ -651,14 +651,13 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
         # against the two-pass forms of the same kernels (nsg_debug_set_c1_moments(0)): statistics to 1e-5, weight gradient to 1e-2
         # (the two-pass weight gradient rounds dh to bf16, the one-pass form multiplies the exact bf16 dy)
         from neural_sound_generation_amd import _lib
-        lib = _lib.load()
-        lib.nsg_debug_set_c1_moments.argtypes = [ctypes.c_int32]
-        lib.nsg_debug_set_c1_moments(0)
-        try:
-            y2, mean2, invstd2 = ops.c1conv_bn_relu_forward(imgg, wg, bg, gag, beg, training=True, out_dtype=dt)
-            dw2p, dbias2p, dgm2p, dbt2p = ops.c1conv_bn_relu_backward(imgg, wg, bg, gag, beg, mean, invstd, dyg)
-        finally:
-            lib.nsg_debug_set_c1_moments(1)
+        with _lib.use_diag() as lib:        # the diagnostics build carries the switch; the product library has only the one-pass form
+            lib.nsg_debug_set_c1_moments(0)
+            try:
+                y2, mean2, invstd2 = ops.c1conv_bn_relu_forward(imgg, wg, bg, gag, beg, training=True, out_dtype=dt)
+                dw2p, dbias2p, dgm2p, dbt2p = ops.c1conv_bn_relu_backward(imgg, wg, bg, gag, beg, mean, invstd, dyg)
+            finally:
+                lib.nsg_debug_set_c1_moments(1)
         np.testing.assert_allclose(mean.cpu().numpy(), mean2.cpu().numpy(), rtol=1e-5, atol=5e-6)      # (h itself carries 2^-17 per product
         np.testing.assert_allclose(invstd.cpu().numpy(), invstd2.cpu().numpy(), rtol=1e-5)             #  in the two-pass form)
         _close(dgm.cpu(), dgm2p.cpu(), tol=1e-5, what="one-pass dgamma vs two-pass")
