@@ -48,7 +48,14 @@ NSG_DIAG_SWITCH(int, g_patch_grid_cap, 512)  // nsg_debug_set_patch_grid: workgr
 #define NSG_PATCH_PRIV 1
 #endif
 
-inline int patch_grid(int ntiles) { return (g_patch_grid_cap > 0 && ntiles > g_patch_grid_cap) ? g_patch_grid_cap : ntiles; }
+// Workgroups along x for ntiles pixel tiles and ntn channel tiles (blockIdx.y): x * ntn workgroups are resident at once (two per
+// CU), each walks its channel tile's pixel tiles with a grid stride.  (Round 2 capped x alone: with C_out = 256 the 1024
+// workgroups ran as two batches of 512, 1.25 tiles each = four tile times for 2.5 tiles of work per slot; now three.)
+inline int patch_grid(int ntiles, int ntn)
+{
+    const int cap = g_patch_grid_cap > 0 ? (g_patch_grid_cap / ntn > 0 ? g_patch_grid_cap / ntn : 1) : 0;
+    return (cap > 0 && ntiles > cap) ? cap : ntiles;
+}
 
 constexpr int PG_MAX_JOBS = 16;
 constexpr int PG_MAX_TAPS = 64;
@@ -542,7 +549,7 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
-    const int gx = patch_grid(p.ntiles);
+    const int gx = patch_grid(p.ntiles, ntiles_n);
     hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }

@@ -56,7 +56,8 @@ template <int DP, bool USE_MFMA>
 __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict__ x, const float *__restrict__ e,
                                                          const float *__restrict__ x2, const float *__restrict__ c2,
                                                          int64_t N, int D, int K, int64_t *__restrict__ idx_out,
-                                                         float *__restrict__ codes_out, float *__restrict__ dmin_out)
+                                                         float *__restrict__ codes_out, float *__restrict__ dmin_out,
+                                                         int tiles_per_slice, float *__restrict__ part_d, int *__restrict__ part_i)
 {
     constexpr int NS = DP / 2;           // MFMA steps (2 d's per step)
     constexpr int EP = DP + 1;           // LDS pitch of a code row (odd: conflict-free ds_read_b32)
@@ -106,7 +107,10 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) { best[r] = INFINITY; bidx[r] = 0x7fffffff; }
 
-    const int ntiles = (K + 31) / 32;
+    // this block's slice of the codebook: tiles [ct0, ct1) (the whole codebook unless the launch is split, nsg_vq_slices)
+    const int ntiles_all = (K + 31) / 32;
+    const int ct0 = (int)blockIdx.y * tiles_per_slice;
+    const int ntiles = ct0 + tiles_per_slice < ntiles_all ? ct0 + tiles_per_slice : ntiles_all;
     v4f re[EJ];
     unsigned okmask = 0;
     // unconditional loads (clamped address), zero-fill at LDS-store time: no wait behind a load
@@ -151,12 +155,12 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
         }
     };
 
-    gload(0);
+    gload(ct0);
     lstore(0);
     __syncthreads();
 
-    for (int ct = 0; ct < ntiles; ++ct) {
-        const int cur = ct & 1;
+    for (int ct = ct0; ct < ntiles; ++ct) {
+        const int cur = (ct - ct0) & 1;
         if (ct + 1 < ntiles) gload(ct + 1);
         const int code = ct * 32 + l31;
         const float c2v = code < K ? c2[code] : INFINITY;
@@ -206,6 +210,13 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
             const int oi = __shfl_xor(bi, off, 64);
             if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
+        if (part_d != nullptr) {        // sliced launch: this slice's first minimum; nsg_launch_vq_combine finishes the job
+            if (l31 == 0) {
+                const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < N) { part_d[(size_t)blockIdx.y * N + row] = bv; part_i[(size_t)blockIdx.y * N + row] = bi; }
+            }
+            continue;
+        }
         if (bi == 0x7fffffff) bi = 0;
         if (l31 == 0) {
             const int rl = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
             }
         }
     }
-    if (codes_out == nullptr) return;
+    if (codes_out == nullptr || part_d != nullptr) return;
     __syncthreads();
     // ---- gather: codes_out[row] = e[idx[row]]  (vector_quantization.py:40-42) ----
     if (vec_ok && nsg_aligned16_dev(codes_out)) {
@@ -352,9 +363,74 @@ __global__ void ema_codes_kernel(float *e, const float *ema_n, float *ema_s, con
     }
 }
 
+// First minimum over the S slices of a sliced search (slice order = code order, strict <: the first minimal index), then the
+// gathers the unsplit kernels do themselves.  One block per 128 rows.
+__global__ __launch_bounds__(256) void vq_combine_kernel(const float *__restrict__ pd, const int *__restrict__ pi, int S, int64_t N, int D, int K,
+                                                         const float *__restrict__ e, int64_t *__restrict__ idx_out,
+                                                         float *__restrict__ codes_out, float *__restrict__ dmin_out,
+                                                         bf16_t *__restrict__ codes_lp, int lp_relu,
+                                                         const float *__restrict__ clip_rows, int64_t rows_per_clip)
+{
+    __shared__ int sidx[128];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    if (tid < 128) {
+        const int64_t row = row0 + tid;
+        int bi = 0;
+        if (row < N) {
+            float bv = INFINITY;
+            bi = 0x7fffffff;
+            for (int sl = 0; sl < S; ++sl) {
+                const float v = pd[(size_t)sl * N + row];
+                const int i = pi[(size_t)sl * N + row];
+                if (v < bv) { bv = v; bi = i; }
+            }
+            if (bi == 0x7fffffff) bi = 0;
+            idx_out[row] = (int64_t)bi;
+            if (dmin_out) dmin_out[row] = bv;
+        }
+        sidx[tid] = bi;
+    }
+    if (codes_out == nullptr && codes_lp == nullptr) return;
+    __syncthreads();
+    const bool vec = (D & 7) == 0 && nsg_aligned16_dev(e) && (!codes_out || nsg_aligned16_dev(codes_out));
+    if (!vec) {         // (odd widths: the fp32 search only; the bf16 outputs need D % 8 == 0)
+        for (int f = tid; f < 128 * D; f += 256) {
+            const int r = f / D, d = f - r * D;
+            if (row0 + r < N && codes_out) codes_out[(row0 + r) * D + d] = e[(size_t)sidx[r] * D + d];
+        }
+        return;
+    }
+    const int D8 = D >> 3;
+    for (int f = tid; f < 128 * D8; f += 256) {
+        const int r = f / D8, d8 = (f - r * D8) * 8;
+        const int64_t row = row0 + r;
+        if (row >= N) continue;
+        const float *src = e + (size_t)sidx[r] * D + d8;
+        const v4f a = *reinterpret_cast<const v4f *>(src), b = *reinterpret_cast<const v4f *>(src + 4);
+        if (codes_out) {
+            *reinterpret_cast<v4f *>(codes_out + row * D + d8) = a;
+            *reinterpret_cast<v4f *>(codes_out + row * D + d8 + 4) = b;
+        }
+        if (codes_lp) {
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (clip_rows) {
+                const float *cr = clip_rows + (size_t)(row / rows_per_clip) * D + d8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += cr[i];
+            }
+            if (lp_relu) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            Elem<bf16_t>::store16(codes_lp + row * D + d8, v);
+        }
+    }
+}
+
 template <int DP>
 int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const float *c2, int64_t N, int D, int K,
-              int64_t *idx, float *codes, float *dmin, hipStream_t s)
+              int64_t *idx, float *codes, float *dmin, float *part_d, int *part_i, hipStream_t s)
 {
     constexpr int XC = (DP < 64) ? DP : 64;
     const size_t lds_e = (size_t)2 * 32 * (DP + 1) * sizeof(float);
@@ -368,14 +444,47 @@ int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const 
                                              reinterpret_cast<const void *>(&vq_forward_kernel<DP, false>)}, lds, "vq_forward");
         if (rc != NSG_OK) return rc;
     }
+    const int S = part_d ? nsg_vq_slices(N, K) : 1;
+    const int tps = (int)nsg_cdiv(nsg_cdiv(K, 32), S);
     if (mfma)
-        hipLaunchKernelGGL((vq_forward_kernel<DP, true>), dim3((unsigned)nb), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin);
+        hipLaunchKernelGGL((vq_forward_kernel<DP, true>), dim3((unsigned)nb, (unsigned)S), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin, tps, part_d, part_i);
     else
-        hipLaunchKernelGGL((vq_forward_kernel<DP, false>), dim3((unsigned)nb), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin);
-    return nsg_check_launch("vq_forward_kernel");
+        hipLaunchKernelGGL((vq_forward_kernel<DP, false>), dim3((unsigned)nb, (unsigned)S), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin, tps, part_d, part_i);
+    int rc = nsg_check_launch("vq_forward_kernel");
+    if (rc == NSG_OK && part_d) rc = nsg_launch_vq_combine(part_d, part_i, S, N, D, K, e, idx, codes, dmin, nullptr, 0, nullptr, 0, s);
+    return rc;
 }
 
 }  // namespace
+
+int nsg_vq_slices(int64_t N, int K)
+{
+    const int64_t nb = nsg_cdiv(N, 128);
+    if (nb <= 0) return 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int S = 1; S <= 8; S *= 2) {
+        if (S > 1 && nsg_cdiv(K, 32) / S < 16) break;                       // a slice keeps at least 16 code tiles (a block's fixed costs)
+        const int64_t units = nb * S;
+        const double eff = (double)units / (double)(nsg_cdiv(units, NSG_SEARCH_SLOTS) * NSG_SEARCH_SLOTS);
+        if (eff > best_eff * 1.05) { best_eff = eff; best = S; }            // more slices only for a real gain (they cost a combine pass)
+    }
+    return best;
+}
+
+size_t nsg_vq_slice_bytes(int64_t N, int K)
+{
+    const int S = nsg_vq_slices(N, K);
+    return S > 1 ? 2 * nsg_align_up((size_t)S * (size_t)N * sizeof(float), 256) : 0;
+}
+
+int nsg_launch_vq_combine(const float *pd, const int *pi, int S, int64_t N, int D, int K, const float *e, int64_t *idx, float *codes,
+                          float *dmin, bf16_t *codes_lp, int lp_relu, const float *clip_rows, int64_t rows_per_clip, hipStream_t s)
+{
+    hipLaunchKernelGGL(vq_combine_kernel, dim3((unsigned)nsg_cdiv(N, 128)), dim3(256), 0, s, pd, pi, S, N, D, K, e, idx, codes, dmin, codes_lp,
+                       lp_relu, clip_rows, rows_per_clip);
+    return nsg_check_launch("vq_combine_kernel");
+}
 
 extern "C" {
 
@@ -383,7 +492,7 @@ size_t nsg_vq_workspace_bytes(int64_t N, int32_t D, int32_t K)
 {
     (void)D;
     if (N < 0 || K < 0) return 0;
-    return nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256);
+    return nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256) + nsg_vq_slice_bytes(N, K);
 }
 
 int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream)
@@ -406,16 +515,23 @@ static int vq_forward_impl(bool mfma, const float *x, const float *e, int64_t N,
                 "nsg_vq_forward: workspace too small");
     float *x2 = reinterpret_cast<float *>(workspace);
     float *c2 = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + nsg_align_up((size_t)N * sizeof(float), 256));
+    float *part_d = nullptr;
+    int *part_i = nullptr;
+    if (nsg_vq_slices(N, K) > 1) {
+        char *base = reinterpret_cast<char *>(workspace) + nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256);
+        part_d = reinterpret_cast<float *>(base);
+        part_i = reinterpret_cast<int *>(base + nsg_vq_slice_bytes(N, K) / 2);
+    }
     int rc = nsg_rowsumsq(x, N, D, x2, stream);
     if (rc) return rc;
     rc = nsg_rowsumsq(e, K, D, c2, stream);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (D <= 16) return launch_vq<16>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    if (D <= 32) return launch_vq<32>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    if (D <= 64) return launch_vq<64>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    if (D <= 128) return launch_vq<128>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
-    return launch_vq<256>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, s);
+    if (D <= 16) return launch_vq<16>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, part_d, part_i, s);
+    if (D <= 32) return launch_vq<32>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, part_d, part_i, s);
+    if (D <= 64) return launch_vq<64>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, part_d, part_i, s);
+    if (D <= 128) return launch_vq<128>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, part_d, part_i, s);
+    return launch_vq<256>(mfma, x, e, x2, c2, N, D, K, idx_out, codes_out, dmin_out, part_d, part_i, s);
 }
 
 int nsg_vq_forward(const float *x, const float *e, int64_t N, int32_t D, int32_t K, int64_t *idx_out, float *codes_out,
