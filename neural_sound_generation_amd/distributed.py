@@ -73,6 +73,30 @@ def allreduce_sum_(flat: torch.Tensor, group=None, async_op: bool = False):
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+class TwoPartAllReduce:
+    """Sum-all-reduce of one flat buffer in two collectives: start_back() sends [split:] as soon as that part is final (it runs
+    on the collective's own stream / thread beside whatever still fills [:split]); finish() sends [:split] and joins both.
+    Without a start_back() since the last finish(), finish() is one collective over the whole buffer.  Same sums either way."""
+
+    def __init__(self, flat: torch.Tensor, split: int, group=None):
+        self.flat, self.split, self.group = flat, int(split), group
+        self.work = None
+
+    def start_back(self):
+        if world_size(self.group) > 1 and 0 < self.split < self.flat.numel() and self.work is None:
+            self.work = allreduce_sum_(self.flat[self.split:], self.group, async_op=True)
+
+    def finish(self):
+        if world_size(self.group) == 1:
+            return
+        work, self.work = self.work, None
+        if work is None:
+            allreduce_sum_(self.flat, self.group)
+        else:
+            allreduce_sum_(self.flat[:self.split], self.group)
+            work.wait()
+
+
 def shard_batch(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """Rank r takes clips [r*B/world, (r+1)*B/world) of the global batch."""
     if batch.size(0) % world != 0:

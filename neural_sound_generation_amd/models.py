@@ -101,6 +101,9 @@ class ResBlock(nn.Module):
             xn = x.permute(0, 2, 3, 1)
             if xn.is_contiguous():                   # channels_last storage: ReLU in place by the library's own kernel
                 ops.convert(xn, torch.float32, out=xn, relu=True)
+                # a raw kernel wrote through the pointer: tell autograd, so that an upstream op that saved x raises "modified by
+                # an inplace operation" exactly as the reference's nn.ReLU(True) makes it (the NCHW branch below goes through copy_)
+                torch.autograd.graph.increment_version(x)
             else:
                 x.copy_(Fn.to_nchw_view(ops.convert(xn.contiguous(), torch.float32, relu=True)))
         return y

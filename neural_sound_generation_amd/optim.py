@@ -122,6 +122,10 @@ class FlatAdam(torch.optim.Optimizer):
         if self.flat_param.is_cuda:
             ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr=g["lr"],
                           beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], grad_scale=grad_scale)
+            # the kernel updated the parameters through raw pointers: bump autograd's version counters (each Parameter keeps its
+            # own, `p.data = view` does not share the bucket's), so a backward through a graph built BEFORE this step raises
+            # instead of differentiating against new values
+            torch.autograd.graph.increment_version(self._params)
         else:
             raise RuntimeError("FlatAdam.step: parameters are not on a GPU; this path has no CPU fallback")
         return loss

@@ -64,6 +64,16 @@ class FusedTrainStep:
         self.g_code = None if self.ema else self.opt.grads_for([self.codebook])[0]
         self.spk = getattr(model, "speaker_embedding", None)
         self.g_spk = self.opt.grads_for([self.spk.weight])[0] if self.spk is not None else None
+        # Data parallel: the communication buffer is [encoder | codebook | decoder | speaker table | EMA statistics]; everything
+        # from the decoder's first gradient on is final when the decoder's backward has been enqueued, BEFORE the encoder's
+        # backward starts, so that part is all-reduced on the collective's own stream beside the encoder backward and only the
+        # front part waits for the end of the step (two collectives, the first one hidden).
+        lo = self.opt.flat_grad.data_ptr()
+        self._comm_split = (self.g_dec[0].data_ptr() - lo) // 4
+        if not (0 < self._comm_split < self.opt.flat_grad.numel()) or any(t.data_ptr() < self.g_dec[0].data_ptr() for t in self.g_dec):
+            self._comm_split = 0          # (unexpected parameter order: one collective at the end, as before)
+        self._reduce = None               # nsg_dist.TwoPartAllReduce over the communication buffer (made on first use: reserve_tail may still grow it)
+        self._stepping = False            # collectives only from step(): forward_backward() alone never communicates
         # test hook: (N,) int64 code indices to use INSTEAD of the search's (the search still runs and is ignored).  Lets a test
         # compare this mode's backward with another evaluation's on the SAME codes (tests/test_gpu_model.py, bf16 fidelity).
         self.force_indices = None
@@ -130,28 +140,39 @@ class FusedTrainStep:
                 ops.add(gs, None, out=self.g_spk)
             else:
                 self.g_spk.zero_()
+        if self.ema:    # per-code counts and sums of the assigned encoder rows straight into the communication buffer's tail
+            ops.index_add_rows(idx, ze.view(-1, D), K, impl=self.scatter_impl, out=self.ema_s, counts=self.ema_n)
+        self._reduce_back_part()        # decoder, speaker table, EMA statistics: final from here on (no-op on one rank / in a graph)
         # loss_vq = mse(z_q, sg(z_e)) -> codebook; loss_commit = mse(z_e, sg(z_q)) -> encoder,
         # plus the straight-through gradient from the decoder               (train.py:131-134)
         if lean:
             loss_vq, dz = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
                                                 grad_dtype=self.dtype)
             dz = dz.view(ze.shape)
-            if self.ema:    # per-code counts and sums straight into the communication buffer's tail
-                ops.index_add_rows(idx, ze.view(-1, D), K, impl=self.scatter_impl, out=self.ema_s, counts=self.ema_n)
-            else:   # d loss_vq / d e_k = 2/numel * sum over the rows assigned to k of (e_k - z) = 2/numel * (n_k e_k - s_k)
+            if not self.ema:    # d loss_vq / d e_k = 2/numel * sum over the rows assigned to k of (e_k - z) = 2/numel * (n_k e_k - s_k)
                 s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
                 ops.codebook_grad_from_sums(self.codebook.detach(), n, s, 2.0 / ze.numel(), out=self.g_code)
         elif self.ema:
             # EMA codebook (extension): no codebook gradient; per-code counts and sums of the assigned
             # encoder rows are the statistics every rank contributes (summed over ranks in step())
             loss_vq, dz, _ = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, want_dq=False, grad_dtype=self.dtype)
-            ops.index_add_rows(idx, ze.view(-1, D), K, impl=self.scatter_impl, out=self.ema_s, counts=self.ema_n)
         else:
             loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, grad_dtype=self.dtype)
             self._codebook_grad(idx, dq.view(-1, D), K)
         engine.encoder_backward(dz, es, self.encP, gout=self.g_enc)
         self.last_indices = idx
         return loss_recons, loss_vq, loss_vq
+
+    def _reduce_back_part(self):
+        """Start the all-reduce of [decoder | speaker | EMA statistics] (called when they are final: the collective waits for the
+        kernels enqueued so far, then runs on its own stream beside the encoder backward).  step() joins it before Adam."""
+        if self.world > 1 and self._comm_split > 0 and self._stepping and not torch.cuda.is_current_stream_capturing():
+            self._two_part().start_back()
+
+    def _two_part(self):
+        if self._reduce is None or self._reduce.flat.data_ptr() != self.opt.flat_comm.data_ptr() or self._reduce.flat.numel() != self.opt.flat_comm.numel():
+            self._reduce = nsg_dist.TwoPartAllReduce(self.opt.flat_comm, self._comm_split, self.group)
+        return self._reduce
 
     def _codebook_grad(self, idx, dq, K):
         g = ops.index_add_rows(idx, dq, K, impl=self.scatter_impl)
@@ -164,19 +185,26 @@ class FusedTrainStep:
     @torch.no_grad()
     def capture(self, c: torch.Tensor, g: torch.Tensor | None = None, warmup: int = 2):
         """Capture forward_backward for inputs of c's shape.  The warm-up steps are REAL training steps."""
-        for _ in range(warmup):               # first-use work (LDS attributes, workspace growth) must not be captured
-            self.step(c, g)
-        self._static_c = c.clone()
-        self._static_g = g.clone() if g is not None else None
+        # The captured launches carry the scratch buffer's ADDRESS, and ops.WS keeps one buffer per (device, stream).  So the
+        # warm-up steps (first-use work: LDS attributes, workspace growth -- and they are REAL training steps) run on the very
+        # stream the capture then uses: the capture finds the warmed-up buffer under its own key and must not outgrow it.  A
+        # later call on that stream that needs more scratch makes the workspace allocate a new buffer and drop the old one; this
+        # graph holds a reference to the old one (_graph_ws), so its replays never touch memory someone else owns.
+        self._graph_stream = torch.cuda.Stream(device=c.device)
+        self._graph_stream.wait_stream(torch.cuda.current_stream(c.device))
+        with torch.cuda.stream(self._graph_stream):
+            for _ in range(warmup):
+                self.step(c, g)
+            self._static_c = c.clone()
+            self._static_g = g.clone() if g is not None else None
+            ws = ops.WS.current(c.device)              # (this stream's buffer)
+        torch.cuda.current_stream(c.device).wait_stream(self._graph_stream)
         torch.cuda.synchronize()
-        # The captured launches carry the scratch buffer's ADDRESS (ops.WS).  A later call that needs more scratch (a longer
-        # T from the bucketed sampler, eval_losses, the prior, the audio export) makes the workspace allocate a new buffer
-        # and drop the old one; this graph keeps the old one alive, so its replays never touch memory someone else owns.
-        ws = ops.WS.current(c.device)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, stream=self._graph_stream):
             self._graph_losses = self.forward_backward(self._static_c, self._static_g)
-        if ops.WS.current(c.device) is not ws:
+            ws_after = ops.WS.current(c.device)
+        if ws is None or ws_after is not ws:
             self._graph = None
             raise RuntimeError("FusedTrainStep.capture: the workspace grew during capture (warm-up steps must see the captured shapes)")
         self._graph_ws = ws
@@ -194,10 +222,15 @@ class FusedTrainStep:
         if getattr(self, "_graph", None) is not None and c.shape == self._static_c.shape and (g is None) == (self._static_g is None):
             losses = self._replay(c, g)
         else:
-            losses = self.forward_backward(c, g)
+            self._stepping = True
+            try:
+                losses = self.forward_backward(c, g)
+            finally:
+                self._stepping = False
         if self.world > 1:
-            # ONE collective per step: the gradient bucket, and behind it (EMA mode) the per-code counts and sums
-            nsg_dist.allreduce_sum_(self.opt.flat_comm, self.group)
+            # the gradient bucket and behind it (EMA mode) the per-code counts and sums: the back part is already in flight
+            # (_reduce_back_part), the front part (encoder, codebook) goes now; a replayed graph holds no collective: one for all
+            self._two_part().finish()
         self.opt.step(grad_scale=1.0 / self.world)
         if self.ema:
             self.apply_ema()

@@ -126,3 +126,40 @@ def test_state_outside_the_bucket_is_replicated_and_tail_rides_in_the_all_reduce
     assert int(a["sd.encoder.1.num_batches_tracked"]) == 1      # rank 0's perturbed counter (0 + 1), exactly
     assert np.array_equal(a["tail"], np.arange(a["tail"].size, dtype=np.float32) * 3) and np.array_equal(a["tail"], b["tail"])
     assert np.all(a["grad0"] == 3.0) and np.all(b["grad0"] == 3.0)
+
+
+def _two_part_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neural_sound_generation_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    n, split = 4096 + 37, 1536
+    gen = torch.Generator().manual_seed(100 + rank)
+    res = []
+    for use_back in (True, False, True):
+        flat = torch.randn(n, generator=gen)
+        mine = flat.clone()
+        red = D.TwoPartAllReduce(flat, split)
+        if use_back:
+            front_late = torch.randn(split, generator=gen)
+            flat[:split] = float("nan")           # the front part is NOT final yet when the back part goes
+            red.start_back()
+            flat[:split] = front_late             # ... "the encoder backward" fills it meanwhile
+            mine[:split] = front_late
+        red.finish()
+        total = mine.clone()
+        dist.all_reduce(total)                    # the one-collective answer on the same inputs
+        res.append(bool(torch.equal(flat, total)))
+    if rank == 0:
+        np.save(out_path, np.array(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_part_allreduce_equals_one_collective(tmp_path):
+    """FusedTrainStep sends [decoder | speaker | EMA statistics] when the decoder backward is enqueued and [encoder | codebook] at
+    the end of the step: two collectives (the first overlapped) must leave exactly what ONE all-reduce of the buffer leaves."""
+    out = str(tmp_path / "two_part.npy")
+    mp.spawn(_two_part_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).all()

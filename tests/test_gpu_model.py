@@ -133,6 +133,22 @@ def test_resblock_autograd_contract():
         blk.block[5].weight.mul_(2.0)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         y2.sum().backward()
+    # ... and the optimiser's raw-pointer update counts as such a modification (FlatAdam.step bumps the version)
+    blk2 = M.ResBlock(8).to(DEV).train()
+    opt2 = FlatAdam(blk2.parameters(), lr=1e-3)
+    y3 = blk2(x0.clone().to(DEV))
+    opt2.zero_grad()
+    opt2.step()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y3.sum().backward()
+    # the block's in-place ReLU of its ARGUMENT is visible to autograd too: an upstream op that saved that tensor for its own
+    # backward (exp saves its output) must raise, as with the reference's nn.ReLU(True), not return a silently wrong gradient
+    for fmt in (torch.channels_last, torch.contiguous_format):
+        leaf = x0.clone().to(DEV).requires_grad_(True)
+        mid = torch.exp(leaf * 0.1).contiguous(memory_format=fmt)
+        out = blk(mid)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            out.sum().backward()
     # the mel input is data: asking for its gradient is refused loudly, not answered with None
     vq = M.VQVAE(1, 16, 32).to(DEV).train()
     c = torch.rand(2, 1, 80, 32, device=DEV, requires_grad=True)
@@ -907,10 +923,11 @@ def test_hip_graph_replay_is_bitwise_the_eager_step(golden_dir):
 
 
 def test_hip_graph_survives_workspace_growth(golden_dir):
-    """the graph's launches carry the scratch buffer's address.  An eager step on a LARGER batch in between (a
-    longer T from the bucketed sampler falls back to eager) regrows the shared workspace; the graph must keep its own
-    buffer alive: replays after that equal the same sequence run eagerly, bit for bit, even with fresh allocations
-    landing wherever the allocator likes."""
+    """The graph's launches carry the scratch buffer's address, and ops.WS keeps one buffer per (device, stream): capture() warms
+    up and captures on ONE stream, so the buffer it guards is the one the graph uses (the round-2 guard watched the
+    default stream's buffer, which the capture never touched).  A later eager step ON THE GRAPH'S STREAM with a larger batch
+    regrows that very buffer; the graph must keep its own alive: replays after that equal the same sequence run eagerly, bit
+    for bit, even with fresh allocations landing wherever the allocator likes."""
     g = golden(golden_dir, "model_tiny.npz")
     c = torch.from_numpy(g["s0.c"]).to(DEV)
     big = torch.rand(3, 1, 80, 3072, generator=torch.Generator().manual_seed(3)).to(DEV)    # ~70x the captured batch's scratch needs
@@ -922,21 +939,29 @@ def test_hip_graph_survives_workspace_growth(golden_dir):
         st = FusedTrainStep(m, lr=1e-3)
         if use_graph:
             st.capture(c, warmup=2)
-            held = ops.WS.current(c.device)
+            with torch.cuda.stream(st._graph_stream):
+                held = ops.WS.current(c.device)            # the capture stream's buffer = the one baked into the graph
+            assert held is not None and st._graph_ws is held
             addr, size = held.data_ptr(), held.numel()
         else:
             st.step(c); st.step(c)
         st.step(c * 0.5 + 0.1)
-        st.step(big)                              # eager in both arms (shape differs from the captured one): the workspace grows
-        if use_graph:
-            now = ops.WS.current(c.device)
+        if use_graph:                             # the large step, eager, on the graph's own stream: ITS workspace grows
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st._graph_stream):
+                st.step(big)
+                now = ops.WS.current(c.device)
+            torch.cuda.synchronize()
             assert now is not held and now.numel() > size, "the large step was meant to outgrow the captured workspace"
             assert st._graph_ws is held and held.data_ptr() == addr
             del now, held
             hog = [torch.full((size // 4,), float("nan"), device=DEV) for _ in range(4)]   # would land in a freed buffer and be trampled / trample
+        else:
+            st.step(big)
         for _ in range(3):
             l = st.step(c * 0.9 + 0.05)
         if use_graph:
+            torch.cuda.synchronize()
             assert all(bool(torch.isnan(h).all()) for h in hog), "a replay wrote into memory it no longer owned"
         outs.append(([x.item() for x in l], {k: v.clone() for k, v in m.state_dict().items()}))
     assert outs[0][0] == outs[1][0]
