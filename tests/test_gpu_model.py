@@ -144,8 +144,9 @@ def test_resblock_autograd_contract():
     # the block's in-place ReLU of its ARGUMENT is visible to autograd too: an upstream op that saved that tensor for its own
     # backward (exp saves its output) must raise, as with the reference's nn.ReLU(True), not return a silently wrong gradient
     for fmt in (torch.channels_last, torch.contiguous_format):
-        leaf = x0.clone().to(DEV).requires_grad_(True)
-        mid = torch.exp(leaf * 0.1).contiguous(memory_format=fmt)
+        leaf = x0.clone().to(DEV).contiguous(memory_format=fmt).requires_grad_(True)
+        mid = torch.exp(leaf * 0.1)                  # (keeps the memory format; exp saves THIS tensor for its backward)
+        assert mid.is_contiguous(memory_format=fmt)
         out = blk(mid)
         with pytest.raises(RuntimeError, match="modified by an inplace operation"):
             out.sum().backward()
