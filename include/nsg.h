@@ -197,7 +197,11 @@ NSG_API size_t nsg_conv_workspace_bytes(const nsg_conv_desc *d);
 
 /* y = conv(x) + bias.  Replaces F.conv2d / F.conv_transpose2d as called by nn.Conv2d /
  * nn.ConvTranspose2d.forward at src/models.py:150,153,165,168,179,182.
- * flags: NSG_RELU_IN (the preceding nn.ReLU fused into the load), NSG_TANH_OUT (models.py:183). */
+ * flags: NSG_RELU_IN (the preceding nn.ReLU fused into the load), NSG_TANH_OUT (models.py:183).
+ * CONTRACT for w_fwd here and w_dgrad in nsg_conv_dgrad*: the pointer is an image written by nsg_pack_conv_weights(_batch) for
+ * the SAME descriptor into a buffer of nsg_packed_weight_floats(d) elements.  For the bf16 shapes the patch-staged kernel takes
+ * that count is TWICE taps * C_out * C_in: the kernel reads the fragment-ordered copy that the packer put behind the plain image
+ * and cannot tell a shorter caller-made buffer from a packed one (it would read past it).  tests/test_abi.py pins the sizes. */
 NSG_API int nsg_conv_forward(const nsg_conv_desc *d, const void *x, const void *w_fwd, const float *bias, void *y,
                              int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
 

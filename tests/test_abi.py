@@ -74,6 +74,20 @@ def test_size_queries():
     assert lib.nsg_reduce_workspace_bytes(10) >= 8
 
 
+def test_packed_weight_image_sizes_include_the_fragment_ordered_copy():
+    """nsg_conv_forward / nsg_conv_dgrad read, for the bf16 shapes gemm_patch.hip takes, a fragment-ordered copy BEHIND the plain
+    [tap][n][c] image: the allocation size the header tells callers to use must account for it -- and must not
+    for the shapes that have none."""
+    lib = _lib.load()
+    def n(desc):
+        return lib.nsg_packed_weight_floats(ctypes.byref(desc))
+    plain = 9 * 128 * 128
+    assert n(_lib.ConvDesc(2, 20, 64, 128, 20, 64, 128, 3, 1, 1, 0, _lib.NSG_BF16)) == 2 * plain          # bf16 3x3 128->128: twin
+    assert n(_lib.ConvDesc(2, 20, 64, 128, 20, 64, 128, 3, 1, 1, 0, _lib.NSG_F32)) == plain               # fp32: none
+    assert n(_lib.ConvDesc(2, 20, 64, 32, 20, 64, 32, 3, 1, 1, 0, _lib.NSG_BF16)) == 9 * 32 * 32          # narrow bf16: none
+    assert n(_lib.ConvDesc(2, 20, 64, 256, 40, 128, 256, 4, 2, 1, 1, _lib.NSG_BF16)) == 2 * 16 * 256 * 256   # transposed 4/2/1, D = 256
+
+
 def test_gather_gemm_rejects_tensors_past_its_32_bit_row_offsets():
     """A transposed conv's output is 4x its input: (820, 20, 256, 128) bf16 passes the 4 GiB operand limit but the
     (820, 40, 512, 128) output has more than 2^31 elements, which the kernel's int row offsets cannot address
