@@ -44,6 +44,9 @@ NSG_DIAG_SWITCH(int, g_patch_grid_cap, 512)  // nsg_debug_set_patch_grid: workgr
 #ifndef NSG_PATCH_WDEPTH
 #define NSG_PATCH_WDEPTH 0      // 1: 4-tap jobs keep two weight buffers (fragments one tap ahead, as in round 2)
 #endif
+#ifndef NSG_PATCH_EPIPF
+#define NSG_PATCH_EPIPF 1       // 0: fused operands fetched at the start of the epilogue; 1: in the job's last tap except for ADD + MASK; 2: always
+#endif
 #ifndef NSG_PATCH_PRIV
 #define NSG_PATCH_PRIV 1
 #endif
@@ -102,7 +105,12 @@ struct PatchGemmParams {
 // into 64-byte output segments (4 lanes x 16 bytes per pixel) through a staging region of its own -- no workgroup barrier in
 // the epilogue (the staged form has eight per tile), LDS writes / reads / stores of consecutive tile rows software-pipelined,
 // and the fused add / mask operands are fetched inside the job's LAST tap instead of at the start of the epilogue.
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0), bool PRIV = (NSG_PATCH_PRIV != 0)>
+// Measured (same box, isolated launches on post-ReLU-like data, us): plain variants 196 / 323 / 367 wave-private against 198-202 /
+// 327 / 374 staged (3x3, 4x4-s2, transposed); with fused operands the wave-private form LOSES (3x3 add + mask 236 vs 227,
+// transposed + mask 464-475 vs 435-443: a lane's operand loads are 64-byte segments, two waves fetch every 128-byte line of
+// the operand tensors), so those variants keep the staged epilogue (NSG_PATCH_PRIV: 0 none, 1 plain variants, 2 all).
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0),
+          bool PRIV = (NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK)))>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
@@ -312,6 +320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(ADD ? p.epi_add : p.out), 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(MASK ? p.epi_mask : p.out), 0, (int)out_bytes, 0x00020000);
+    // fused operands fetched in the job's last tap (else at the start of the epilogue): not for the ADD + MASK variant, whose
+    // 64 operand registers on top of the tap loop's working set reach the 256-register limit of two waves per SIMD
+    constexpr bool EPI_EARLY = PRIV && (ADD || MASK) && (NSG_PATCH_EPIPF == 2 || (NSG_PATCH_EPIPF == 1 && !(ADD && MASK)));
     // PRIV epilogue state: byte offsets of this lane's 8 output pieces (tile row y, pixel ep + 16 e2; out of range = dropped / zero)
     // and the fused operands fetched for them
     unsigned eoff[4][2];
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         load_b(breg[(J + NB - 1) % NB], qb);
         __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the loads to their first use)
         patch_traffic(std::integral_constant<int, J % LD>{}, t, buf);
-        if constexpr (decltype(LAST)::value && PRIV && (ADD || MASK)) epi_prefetch();
+        if constexpr (decltype(LAST)::value && EPI_EARLY) epi_prefetch();
         __builtin_amdgcn_sched_barrier(0);
         mfma_chain(bq, buf, q, qn);
     };
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             // channels of pixel ep + 16 e2 per lane.  LDS executes one wave's instructions in order, so row y + 1 may be
             // written right after row y's reads are ISSUED: write(y + 1) and read(y + 1) run under the arithmetic and the
             // stores of row y.
-            if constexpr (!(ADD || MASK)) epi_offsets(tile, jb, true);       // (the fused variants did this before the job's taps)
+            if constexpr (!EPI_EARLY) { epi_offsets(tile, jb, true); epi_prefetch(); }      // (else: before / inside the job's taps)
             float *Sw = reinterpret_cast<float *>(smem + 2 * BUF_BYTES + wave * STG_BYTES);
             float *wdst = Sw + x31 * STG_PITCH + 4 * h;
             const float *rsrc = Sw + ep * STG_PITCH + 8 * eq;
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     auto do_job = [&]() __attribute__((always_inline)) {
         if constexpr (STAMP) st_t = now();
         const PatchJob jb = job_entry(cur.job);
-        if constexpr (PRIV && (ADD || MASK)) epi_offsets(cur.tile, jb, jb.flush != 0);    // for the prefetch in the job's last tap
+        if constexpr (EPI_EARLY) epi_offsets(cur.tile, jb, jb.flush != 0);    // for the prefetch in the job's last tap
         advance(pre);
         patch_origin(pre);                  // its pieces are fetched inside this job's taps
         const int qbase = cur.job * NT;
@@ -542,7 +553,8 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
     constexpr size_t BUF_BYTES = (size_t)8 * ((NSLOT + 15) / 16 * 16) * 16;
-    const size_t lds = 2 * BUF_BYTES + (NSG_PATCH_PRIV ? 4 * 32 * 36 * 4 : 0);     // + the four waves' private epilogue staging
+    constexpr bool PRIV = NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK));
+    const size_t lds = 2 * BUF_BYTES + (PRIV ? 4 * 32 * 36 * 4 : 0);     // + the four waves' private epilogue staging
     static LdsOptIn once;
     if (lds > 65536) {
         const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>)}, lds, "patch_gemm");
