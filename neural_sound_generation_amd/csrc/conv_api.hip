@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
             for (int e = 0; e < 8; ++e) v[e] = sp[(size_t)e * j.sc];
             u4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (unsigned)nsg_f2bf(v[2 * e]) | ((unsigned)nsg_f2bf(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) pk[e] = nsg_pack_bf16(v[2 * e], v[2 * e + 1]);
             bf16_t *d = reinterpret_cast<bf16_t *>(j.dst);
             *reinterpret_cast<u4 *>(d + ((size_t)(t * j.NN + n) * j.CC + c)) = pk;
             if (j.frag) *reinterpret_cast<u4 *>(d + total + nsg_frag_index(t, n, c, j.NN, j.CC)) = pk;

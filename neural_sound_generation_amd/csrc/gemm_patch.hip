@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 
     auto load_b = [&](v4f (&bq)[4], int q) {
         const int so = tap_woff(q);
-#ifdef NSG_PATCH_FAKEW     /* timing experiment only (WRONG results): a quarter of the weight-fragment traffic */
+#if defined(NSG_DIAG) && defined(NSG_PATCH_FAKEW)     /* timing experiment (WRONG results, diagnostics builds only): a quarter of the weight-fragment traffic */
         bq[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wlane, so, 0));
         bq[1] = bq[0]; bq[2] = bq[0]; bq[3] = bq[0];
         return;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         }
         unsigned u[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(v[2 * i]) | ((unsigned)nsg_f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) u[i] = nsg_pack_bf16(v[2 * i], v[2 * i + 1]);
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)eoff[y][e2], 0, 0);
     };
@@ -575,6 +575,7 @@ int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
     return launch_patch<PH, PW, NT, false, false, STAMP>(p, ntiles_n, s);
 }
 
+
 }  // namespace
 
 #ifdef NSG_DIAG
@@ -623,8 +624,10 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     p.epi_add = reinterpret_cast<const bf16_t *>(g.epi_add);
     p.epi_mask = reinterpret_cast<const bf16_t *>(g.epi_mask);
     p.B = g.B; p.IH = g.IH; p.IW = g.IW; p.CI = g.CI; p.OH = g.OH; p.OW = g.OW; p.CO = g.CO;
+    constexpr int tcols = 32;                           // columns of a tile
+    constexpr int pw3 = tcols + 2, pw2 = tcols + 1;     // patch widths in slots: 3x3 (halo 1 + 1), the stride-2 forms' parity planes / classes
     p.tiles_y = (int)nsg_cdiv(g.RH, 4);
-    p.tiles_x = (int)nsg_cdiv(g.RW, 32);
+    p.tiles_x = (int)nsg_cdiv(g.RW, tcols);
     const int64_t nt = (int64_t)g.B * p.tiles_y * p.tiles_x;
     if (nt > 0x3fffffff) return NSG_OK;
     p.ntiles = (int)nt;
@@ -644,7 +647,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
             p.jobs[j] = PatchJob{c * 128, (short)-g.pad, (short)-g.pad_w, 0, 0, c + 1 == chunks};
             for (int kh = 0; kh < 3; ++kh)
                 for (int kw = 0; kw < 3; ++kw)
-                    p.taps[j * 9 + kh * 3 + kw] = PatchTap{(kh * 34 + kw) * SLOT_BYTES, wblock(kh * 3 + kw, c)};
+                    p.taps[j * 9 + kh * 3 + kw] = PatchTap{(kh * pw3 + kw) * SLOT_BYTES, wblock(kh * 3 + kw, c)};
         }
     } else if (kind == 1) {
         for (int c = 0; c < chunks; ++c)
@@ -653,7 +656,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
                 p.jobs[j] = PatchJob{c * 128, (short)(ph - 1), (short)(pw - 1), 0, 0, j + 1 == njobs};
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b)
-                        p.taps[j * 4 + a * 2 + b] = PatchTap{(a * 33 + b) * SLOT_BYTES,
+                        p.taps[j * 4 + a * 2 + b] = PatchTap{(a * pw2 + b) * SLOT_BYTES,
                                                            wblock((2 * a + ph) * 4 + (2 * b + pw), c)};
             }
     } else {
@@ -663,7 +666,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
                 p.jobs[j] = PatchJob{c * 128, (short)(py - 1), (short)(px - 1), (short)py, (short)px, c + 1 == chunks};
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b)
-                        p.taps[j * 4 + a * 2 + b] = PatchTap{((1 - a) * 33 + (1 - b)) * SLOT_BYTES,
+                        p.taps[j * 4 + a * 2 + b] = PatchTap{((1 - a) * pw2 + (1 - b)) * SLOT_BYTES,
                                                            wblock(((1 - py) + 2 * a) * 4 + (1 - px) + 2 * b, c)};
             }
         }

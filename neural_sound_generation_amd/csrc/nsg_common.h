@@ -22,6 +22,14 @@ __host__ __device__ __forceinline__ float nsg_bitsf(unsigned u) { return __built
 
 // fp32 -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32); bf16 bits -> fp32 is a 16-bit shift
 __device__ __forceinline__ bf16_t nsg_f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two at once: ONE v_cvt_pk_bf16_f32 (lo = a, hi = b).  (Converting singly and packing by hand costs three instructions per pair.)
+typedef float nsg_v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 nsg_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nsg_pack_bf16(float a, float b)
+{
+    const nsg_v2f f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, nsg_bf16x2));
+}
 __device__ __forceinline__ float nsg_bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 
 // Elem<T>: N = elements per 16-byte access; load16 / store16 move N elements as floats
@@ -48,7 +56,7 @@ template <> struct Elem<bf16_t> {
     {
         unsigned u[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = (unsigned)nsg_f2bf(o[2 * i]) | ((unsigned)nsg_f2bf(o[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) u[i] = nsg_pack_bf16(o[2 * i], o[2 * i + 1]);
         v4f raw = {nsg_bitsf(u[0]), nsg_bitsf(u[1]), nsg_bitsf(u[2]), nsg_bitsf(u[3])};
         *reinterpret_cast<v4f *>(p) = raw;
     }

@@ -104,7 +104,7 @@ template <typename TO> __device__ __forceinline__ void store4(TO *dst, float x0,
         *reinterpret_cast<v4f *>(dst) = v4f{x0, x1, x2, x3};
     } else {
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const v2u pk = {(unsigned)nsg_f2bf(x0) | ((unsigned)nsg_f2bf(x1) << 16), (unsigned)nsg_f2bf(x2) | ((unsigned)nsg_f2bf(x3) << 16)};
+        const v2u pk = {nsg_pack_bf16(x0, x1), nsg_pack_bf16(x2, x3)};
         *reinterpret_cast<v2u *>(dst) = pk;
     }
 }
