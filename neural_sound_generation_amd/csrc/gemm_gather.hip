@@ -496,6 +496,10 @@ int launch_typed(const GatherGemmParams &p, hipStream_t s)
 
 int nsg_gather_gemm_row_tiles(const GatherGemmParams &p)
 {
+    GatherGemmParams q = p;         // (the byte sizes only matter to the launch itself)
+    if (!q.stats) q.stats = reinterpret_cast<float *>(16);
+    const int rec = nsg_patch_gemm_stat_records(q);
+    if (rec > 0) return rec;        // gemm_patch.hip: one record per workgroup
     return (int)nsg_cdiv(p.M, 128) * (p.mode == 0 ? 1 : 4);
 }
 

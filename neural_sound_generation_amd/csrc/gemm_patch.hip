@@ -91,6 +91,7 @@ struct PatchGemmParams {
     int flags;
     unsigned in_bytes, w_bytes;
     unsigned long long *stamps;     // diagnostics build only: [workgroup][8] cycle counts (never read by any kernel)
+    float *stats;                   // STATS variant: [gridDim.y * gridDim.x][3][CO] (count, sum, M2 about the record's mean) of the stored output
     PatchJob jobs[PG_MAX_JOBS];
     PatchTap taps[PG_MAX_TAPS];
 };
@@ -109,8 +110,12 @@ struct PatchGemmParams {
 // 327 / 374 staged (3x3, 4x4-s2, transposed); with fused operands the wave-private form LOSES (3x3 add + mask 236 vs 227,
 // transposed + mask 464-475 vs 435-443: a lane's operand loads are 64-byte segments, two waves fetch every 128-byte line of
 // the operand tensors), so those variants keep the staged epilogue (NSG_PATCH_PRIV: 0 none, 1 plain variants, 2 all).
+// STATS (plain variant, wave-private epilogue): the batch statistics of the BatchNorm that follows, from the store phase -- a lane
+// keeps the same 8 channels for every piece it stores, so it carries their running sums (about a pivot: its first value) across
+// its tiles in registers; one (count, sum, M2) record per workgroup and channel tile at the end, pooled over the lanes in lane
+// order (double).  Of the values AS STORED (rounded to bf16), real pixels only.  Replaces a read pass over the conv's output.
 template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0),
-          bool PRIV = (NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK)))>
+          bool PRIV = (NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK))), bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
     constexpr int NSLOT = PH * PW;
@@ -193,6 +198,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n0 + ech + e] : 0.f;
     const bool relu_out = (p.flags & NSG_RELU_OUT) != 0;
+    static_assert(!STATS || (PRIV && !ADD && !MASK), "statistics ride in the plain variant's wave-private epilogue");
+    float st_sum[STATS ? 8 : 1], st_sq[STATS ? 8 : 1], st_pv[STATS ? 8 : 1], st_cnt = 0.f;
+#pragma unroll
+    for (int e = 0; e < (STATS ? 8 : 1); ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; st_pv[e] = 0.f; }
 
     // The tap table lives in two VGPRs (lane q = entry q) and is read back with v_readlane: a scalar load inside the tap loop
     // would share lgkmcnt with the fragment reads and drain them.
@@ -400,6 +409,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         unsigned u[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) u[i] = nsg_pack_bf16(v[2 * i], v[2 * i + 1]);
+        if constexpr (STATS) {
+            const float live = eoff[y][e2] != OOB ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y0 = nsg_bitsf(u[i] << 16), y1 = nsg_bitsf(u[i] & 0xffff0000u);
+                st_pv[2 * i] = (st_cnt == 0.f) ? y0 : st_pv[2 * i];
+                st_pv[2 * i + 1] = (st_cnt == 0.f) ? y1 : st_pv[2 * i + 1];
+                const float d0 = (y0 - st_pv[2 * i]) * live, d1 = (y1 - st_pv[2 * i + 1]) * live;
+                st_sum[2 * i] += d0;
+                st_sum[2 * i + 1] += d1;
+                st_sq[2 * i] = __builtin_fmaf(d0, d0, st_sq[2 * i]);
+                st_sq[2 * i + 1] = __builtin_fmaf(d1, d1, st_sq[2 * i + 1]);
+            }
+            st_cnt += live;
+        }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(u4{u[0], u[1], u[2], u[3]}, rs_out, (int)eoff[y][e2], 0, 0);
     };
@@ -535,6 +559,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         if (cur.tile >= p.ntiles) break;
         do_job();
     }
+    if constexpr (STATS) {
+        // (count, mean, M2) of each lane, pooled over the 16 lanes that share a channel octet (same wave, same eq; ep = 0 .. 15)
+        // in ep order, in double: one record per workgroup.  The patch buffers are free: every wave is past the last job.
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);      // [17][256]: 8 means, 8 M2s, the count
+        const float inv = st_cnt > 0.f ? 1.f / st_cnt : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[e * 256 + tid] = st_pv[e] + st_sum[e] * inv;
+            red[(8 + e) * 256 + tid] = fmaxf(st_sq[e] - st_sum[e] * st_sum[e] * inv, 0.f);
+        }
+        red[16 * 256 + tid] = st_cnt;
+        __syncthreads();
+        if (tid < 128) {
+            const int ch = tid, wv = ch >> 5, eqq = (ch >> 3) & 3, e = ch & 7;      // channel ch of the tile: wave wv, octet eqq, element e
+            double N = 0.0, S = 0.0;
+            for (int r = 0; r < 16; ++r) {
+                const int t = wv * 64 + r * 4 + eqq;
+                const double n = red[16 * 256 + t];
+                N += n;
+                S += n * (double)red[e * 256 + t];
+            }
+            const double mu = N > 0.0 ? S / N : 0.0;
+            double Q = 0.0;
+            for (int r = 0; r < 16; ++r) {
+                const int t = wv * 64 + r * 4 + eqq;
+                const double n = red[16 * 256 + t];
+                const double dl = (double)red[e * 256 + t] - mu;
+                Q += n > 0.0 ? (double)red[(8 + e) * 256 + t] + n * dl * dl : 0.0;
+            }
+            float *dst = p.stats + (size_t)blockIdx.x * 3 * p.CO + n0 + ch;       // records of one workgroup index x: all channel tiles side by side
+            dst[0] = (float)N;
+            dst[p.CO] = (float)S;
+            dst[2 * p.CO] = (float)Q;
+        }
+    }
     if constexpr (STAMP) {
         if (tid == 0 && p.stamps) {
             unsigned long long *o = p.stamps + 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
@@ -548,27 +608,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
 }
 
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP>
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP, bool STATS = false>
 int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
     constexpr size_t BUF_BYTES = (size_t)8 * ((NSLOT + 15) / 16 * 16) * 16;
     constexpr bool PRIV = NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK));
+    constexpr bool DEEP = NSG_PATCH_DEEP != 0;
     const size_t lds = 2 * BUF_BYTES + (PRIV ? 4 * 32 * 36 * 4 : 0);     // + the four waves' private epilogue staging
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP, DEEP, PRIV, STATS>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
     const int gx = patch_grid(p.ntiles, ntiles_n);
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP, DEEP, PRIV, STATS>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }
 
 template <int PH, int PW, int NT, bool STAMP>
 int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
+    if constexpr (!STAMP && NSG_PATCH_PRIV != 0) {
+        if (p.stats) return launch_patch<PH, PW, NT, false, false, false, true>(p, ntiles_n, s);
+    }
     if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, STAMP>(p, ntiles_n, s);
     if (p.epi_add) return launch_patch<PH, PW, NT, true, false, STAMP>(p, ntiles_n, s);
     if (p.epi_mask) return launch_patch<PH, PW, NT, false, true, STAMP>(p, ntiles_n, s);
@@ -589,7 +653,8 @@ static int patch_kind(const GatherGemmParams &g)
     if (!g_patch_gemm) return -1;
     if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return -1;
     if (g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) return -1;
-    if (g.stats) return -1;      // BatchNorm statistics from the store phase: gemm_gather.hip's epilogue has that form
+    // BatchNorm statistics from the store phase: the plain variant's wave-private epilogue only (else gemm_gather.hip's epilogue)
+    if (g.stats && (NSG_PATCH_PRIV == 0 || g.epi_add || g.epi_mask || (g.flags & NSG_RELU_OUT) || g.stamps)) return -1;
     if (g.CI % 64 != 0 || g.CO % 128 != 0) return -1;
     const int chunks = g.CI / 64;
     int kind;
@@ -602,6 +667,13 @@ static int patch_kind(const GatherGemmParams &g)
     if (njobs > PG_MAX_JOBS || njobs * ntaps > PG_MAX_TAPS) return -1;
     if ((int64_t)g.B * nsg_cdiv(g.RH, 4) * nsg_cdiv(g.RW, 32) > 0x3fffffff) return -1;
     return kind;
+}
+
+// Statistics records a launch with these parameters writes when this file runs it (one per workgroup index x), or 0 when it does not.
+int nsg_patch_gemm_stat_records(const GatherGemmParams &g)
+{
+    if (patch_kind(g) < 0) return 0;
+    return patch_grid((int)((int64_t)g.B * nsg_cdiv(g.RH, 4) * nsg_cdiv(g.RW, 32)), g.CO / 128);
 }
 
 // Runs the launch on the patch-staged kernel when its shape is one this file implements; *handled says whether it did.
@@ -639,6 +711,7 @@ int nsg_launch_patch_gemm(const GatherGemmParams &g, hipStream_t s, bool *handle
     p.flags = g.flags;
     p.in_bytes = g.in_bytes; p.w_bytes = g.w_bytes;
     p.stamps = g.stamps;
+    p.stats = g.stats;
     const int64_t blk = (int64_t)(g.CO / 32) * 4096;    // bytes of one (tap, 64-channel chunk) block of the fragment-ordered image
     auto wblock = [&](int ws, int c) { return (unsigned)(((int64_t)ws * chunks + c) * blk); };
     int j = 0;

@@ -247,6 +247,7 @@ int nsg_launch_vq_combine(const float *pd, const int *pi, int S, int64_t N, int 
 // gemm_patch.hip: the patch-staged bf16 kernel for the shapes it implements (3x3/1, 4x4/2 and the transposed 4/2/1 with
 // C_in % 64 == 0, C_out % 128 == 0, bf16 in and out); p must have in_bytes / w_bytes filled in.  *handled = false -> not run.
 int nsg_launch_patch_gemm(const GatherGemmParams &p, hipStream_t s, bool *handled);
+int nsg_patch_gemm_stat_records(const GatherGemmParams &p);     // statistics records (p.stats) such a launch writes; 0: not taken
 // Returns bytes of partial-slab workspace it will use for these sizes.
 size_t nsg_wgrad_workspace_bytes(int64_t Mp, int ntaps, int A, int C);
 // dst[(a*C + c)*ntaps + t] = sum over slabs (fixed order) of partial; dst fully overwritten.

@@ -113,12 +113,21 @@ def _bump(bn: "BNParams"):
 
 FUSED_OUT_LOSS = _os.environ.get("NSG_FUSED_OUT_LOSS", "1") == "1"  # reconstruction loss + Tanh backward in the output layer's image pass
 FUSED_1X1_BWD = _os.environ.get("NSG_FUSED_1X1_BWD", "1") == "1"    # the 1x1 conv's data and weight gradients in one kernel (C = 128)
+# BatchNorm batch statistics of a patch_gemm layer's output from that kernel's (wave-private) store phase instead of a read pass
+# over the tensor: 1 = every such layer in front of a BatchNorm (the ResBlocks' 3x3 convs, decoder.3), 2 = decoder.3 only (the
+# high-resolution tensor), 0 = off.  Numbers: DESIGN.md section 6.
+PATCH_BN_STATS = int(_os.environ.get("NSG_PATCH_BN_STATS", "1"))
+
+
+def _patch_stats_ok(d, flags) -> bool:
+    return (PATCH_BN_STATS and (PATCH_BN_STATS == 1 or d.transposed) and d.dtype == ops.NSG_BF16 and flags == 0 and d.C_in % 64 == 0
+            and d.C_out % 128 == 0 and d.k_w == 0 and ((d.k == 3 and d.stride == 1) or (d.k == 4 and d.stride == 2)))
 
 
 def _conv_bn(d, x, wf, conv: ConvParams, bn: BNParams, training: bool, flags=0):
     """conv (+fused input ReLU) followed by BatchNorm statistics: one fused call in training mode
     (the statistics come out of the conv epilogue), two calls in eval mode."""
-    if training and FUSED_BN_STATS:
+    if training and (FUSED_BN_STATS or _patch_stats_ok(d, flags)):
         h, mean, invstd = ops.conv_forward_bnstats(d, x, wf, conv.bias, flags=flags, running_mean=bn.running_mean,
                                                    running_var=bn.running_var)
         _bump(bn)
