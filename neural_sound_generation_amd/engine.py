@@ -116,7 +116,9 @@ FUSED_1X1_BWD = _os.environ.get("NSG_FUSED_1X1_BWD", "1") == "1"    # the 1x1 co
 # BatchNorm batch statistics of a patch_gemm layer's output from that kernel's (wave-private) store phase instead of a read pass
 # over the tensor: 1 = every such layer in front of a BatchNorm (the ResBlocks' 3x3 convs, decoder.3), 2 = decoder.3 only (the
 # high-resolution tensor), 0 = off.  Numbers: DESIGN.md section 6.
-PATCH_BN_STATS = int(_os.environ.get("NSG_PATCH_BN_STATS", "1"))
+# Measured in the step (same box, alternating): off 8.42 / 8.45 ms, decoder.3 only 8.26 / 8.35, all five 8.33 / 8.26 -- while the
+# conv kernel's in-region rate is 978 / 974, 974 / 960 and 927 / 935 TF: the one high-resolution pass is nearly all of the gain.
+PATCH_BN_STATS = int(_os.environ.get("NSG_PATCH_BN_STATS", "2"))
 
 
 def _patch_stats_ok(d, flags) -> bool:
