@@ -104,3 +104,12 @@ def test_gather_gemm_rejects_tensors_past_its_32_bit_row_offsets():
     # one clip fewer fits: the guard must not fire early (it would launch, so only the pure checks are exercised up to here)
     d = _lib.ConvDesc(1 << 20, 20, 256, 128, 40, 512, 128, 4, 2, 1, 1, _lib.NSG_BF16)   # the row count itself overflows
     assert lib.nsg_conv_forward(ctypes.byref(d), fake, fake, null, fake, 0, fake, 1 << 30, null) == -2
+
+
+def test_loader_refuses_a_library_of_another_abi_version(monkeypatch):
+    """entry points changed signature under an unchanged NSG_VERSION, and a stale libnsg.so then took a stream handle
+    for a data pointer.  NSG_VERSION is now bumped on any signature change and the loader compares it."""
+    lib = _lib.load()
+    monkeypatch.setattr(_lib, "NSG_VERSION", lib.nsg_version() + 1)
+    with pytest.raises(_lib.NsgError, match="ABI version"):
+        _lib._bind(ctypes.CDLL(_lib.LIB_PATH))
