@@ -238,9 +238,9 @@ int nsg_launch_gather_gemm(const GatherGemmParams &p, hipStream_t s);
 // the resident slots evenly (BASELINE configs[3]: 640 blocks on 512 slots = two rounds for 1.25 rounds of work), the codebook is
 // cut into S slices (blockIdx.y), each block reports its slice's first minimum per row, and a combine pass takes the first
 // minimum over the slices in slice order -- the same (distance, index) the unsplit search returns, bit for bit -- and gathers.
-constexpr int NSG_SEARCH_SLOTS = 512;                       // resident search blocks on an MI355X (256 CUs x 2; speed only)
-int nsg_vq_slices(int64_t N, int K);                        // S: 1, 2, 4 or 8
-size_t nsg_vq_slice_bytes(int64_t N, int K);                // [S][N] floats + [S][N] ints behind the searches' other workspace; 0 for S = 1
+constexpr int NSG_SEARCH_CUS = 256;                         // CUs of an MI355X (speed only): two search blocks per CU up to D = 128, one beyond
+int nsg_vq_slices(int64_t N, int D, int K);                 // S: 1, 2, 4 or 8
+size_t nsg_vq_slice_bytes(int64_t N, int D, int K);         // [S][N] floats + [S][N] ints behind the searches' other workspace; 0 for S = 1
 // idx / dmin / codes / bf16 codes (each optional except idx) from the S partial results; clip_rows as in nsg_vq_forward_bf16x3_cond
 int nsg_launch_vq_combine(const float *pd, const int *pi, int S, int64_t N, int D, int K, const float *e, int64_t *idx, float *codes,
                           float *dmin, bf16_t *codes_lp, int lp_relu, const float *clip_rows, int64_t rows_per_clip, hipStream_t s);

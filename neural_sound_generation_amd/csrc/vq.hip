@@ -12,6 +12,10 @@
 #include "nsg_common.h"
 #include <math.h>
 
+#ifndef NSG_VQ_W1_DP
+#define NSG_VQ_W1_DP 256      // from this padded width on: one wave per SIMD (no spills) instead of two
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -53,16 +57,22 @@ __global__ void rowsumsq_kernel(const float *__restrict__ v, int64_t rows, int D
 // double-buffered LDS; each wave keeps its 32 rows of x in DP/2 registers as MFMA A fragments.
 // ------------------------------------------------------------------------------------------------
 template <int DP, bool USE_MFMA>
-__global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict__ x, const float *__restrict__ e,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(USE_MFMA && DP < NSG_VQ_W1_DP ? 2 : 1))) void vq_forward_kernel(const float *__restrict__ x, const float *__restrict__ e,
                                                          const float *__restrict__ x2, const float *__restrict__ c2,
                                                          int64_t N, int D, int K, int64_t *__restrict__ idx_out,
                                                          float *__restrict__ codes_out, float *__restrict__ dmin_out,
                                                          int tiles_per_slice, float *__restrict__ part_d, int *__restrict__ part_i)
 {
     constexpr int NS = DP / 2;           // MFMA steps (2 d's per step)
-    constexpr int EP = DP + 1;           // LDS pitch of a code row (odd: conflict-free ds_read_b32)
+    // LDS image of a code row: [the NS even-d values | the NS odd-d values | 4 floats of padding].  Lane (l31, h) needs e[d = 2 s + h]
+    // for s = 0 .. NS - 1 in order: in this image that is NS CONSECUTIVE floats from h * NS, fetched four steps per ds_read_b128;
+    // pitch = DP + 4 floats = 4 (mod 64 banks): the 16 rows of a b128 lane group sit on 16 different 4-bank groups.  (Round 2 kept
+    // the row as it is in memory and read one ds_read2_b32 per two steps; hipcc gave every read the same destination registers and
+    // an s_waitcnt lgkmcnt(0), so each pair of MFMAs waited out a whole LDS round trip: 0.45-0.6 of the fp32 MFMA rate.)
+    constexpr int EP = DP + 4;
     constexpr int XC = (DP < 64) ? DP : 64;  // x staging chunk (d's)
     constexpr int XP = XC + 1;
+    static_assert(NS % 4 == 0, "four MFMA steps per 16-byte fragment read");
     constexpr int EJ = (32 * DP / 4 + 255) / 256;  // float4 per thread per code tile
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,7 +87,45 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
 
     // ---- x rows -> A fragments: a[s] = x[row0 + wave*32 + l31][2s + h] ----
     float a[NS];
-    {
+    if ((D & 3) == 0 && nsg_aligned16_dev(x)) {
+        // 16-byte loads, all of a chunk's in flight at once, into an image de-interleaved like the code rows ([even d | odd d | pad],
+        // pitch XC + 4): the lane's fragments are XC / 2 consecutive floats = XC / 8 ds_read_b128.  (Round 2 staged the rows with
+        // one 4-byte load per thread per loop trip -- a serial chain of global-load latencies per block: 578 of the search's
+        // 1 199 us at K = 512, D = 128 did not scale with K.)
+        constexpr int XPV = XC + 4, Q4 = XC / 4, XJ = 128 * Q4 / 256;          // float4 per row chunk, per thread
+        static_assert(128 * Q4 % 256 == 0 && XC % 8 == 0, "whole float4 per thread, whole b128 per fragment group");
+        float *Xs = smem;  // [128][XPV]
+        typedef float v2f_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < DP / XC; ++c) {
+            const int d0 = c * XC;
+            v4f t[XJ];
+#pragma unroll
+            for (int i = 0; i < XJ; ++i) {
+                const int f4 = tid + 256 * i;
+                const int r = f4 / Q4, q = f4 - r * Q4;
+                const int64_t row = row0 + r;
+                const bool ok = row < N && d0 + 4 * q < D;
+                const v4f v = *reinterpret_cast<const v4f *>(x + (ok ? row * D + d0 + 4 * q : 0));      // clamped, unconditional
+                t[i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < XJ; ++i) {
+                const int f4 = tid + 256 * i;
+                const int r = f4 / Q4, q = f4 - r * Q4;
+                *reinterpret_cast<v2f_ *>(Xs + r * XPV + 2 * q) = v2f_{t[i].x, t[i].z};
+                *reinterpret_cast<v2f_ *>(Xs + r * XPV + XC / 2 + 2 * q) = v2f_{t[i].y, t[i].w};
+            }
+            __syncthreads();
+            const float *src = Xs + (wave * 32 + l31) * XPV + h * (XC / 2);
+#pragma unroll
+            for (int j = 0; j < XC / 8; ++j) {
+                const v4f v = *reinterpret_cast<const v4f *>(src + 4 * j);
+                a[c * (XC / 2) + 4 * j] = v.x; a[c * (XC / 2) + 4 * j + 1] = v.y; a[c * (XC / 2) + 4 * j + 2] = v.z; a[c * (XC / 2) + 4 * j + 3] = v.w;
+            }
+            __syncthreads();
+        }
+    } else {
         float *Xs = smem;  // [128][XP]
 #pragma unroll
         for (int c = 0; c < DP / XC; ++c) {
@@ -149,8 +197,10 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
             const int cr = f / (DP / 4), d4 = (f - cr * (DP / 4)) * 4;
             if (cr < 32) {
                 const bool ok = (okmask >> j) & 1u;
-                float *dst = es + cr * EP + d4;
-                dst[0] = ok ? re[j].x : 0.f; dst[1] = ok ? re[j].y : 0.f; dst[2] = ok ? re[j].z : 0.f; dst[3] = ok ? re[j].w : 0.f;
+                float *dst = es + cr * EP + (d4 >> 1);          // d4 % 4 == 0: (x, z) are the even d's, (y, w) the odd ones
+                typedef float v2f_ __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<v2f_ *>(dst) = v2f_{ok ? re[j].x : 0.f, ok ? re[j].z : 0.f};
+                *reinterpret_cast<v2f_ *>(dst + NS) = v2f_{ok ? re[j].y : 0.f, ok ? re[j].w : 0.f};
             }
         }
     };
@@ -164,22 +214,34 @@ __global__ __launch_bounds__(256) void vq_forward_kernel(const float *__restrict
         if (ct + 1 < ntiles) gload(ct + 1);
         const int code = ct * 32 + l31;
         const float c2v = code < K ? c2[code] : INFINITY;
-        const float *es = Es + cur * 32 * EP + l31 * EP + h;
+        const float *es = Es + cur * 32 * EP + l31 * EP + h * NS;
 
         v16f acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if (USE_MFMA) {
+            // the same chain, s = 0 .. NS - 1 in order; the fragment of steps 4 j + 4 .. + 7 is in flight under the MFMAs of 4 j .. + 3
+            v4f bq[2];
+            bq[0] = *reinterpret_cast<const v4f *>(es);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // (the first fragment: its own group, or the pairs below slip by one)
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], es[2 * s], acc, 0, 0, 0);
+            for (int j = 0; j < NS / 4; ++j) {
+                if (j + 1 < NS / 4) bq[(j + 1) & 1] = *reinterpret_cast<const v4f *>(es + 4 * (j + 1));
+                const v4f b = bq[j & 1];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * j], b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * j + 1], b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * j + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * j + 3], b.w, acc, 0, 0, 0);
+                if (j + 1 < NS / 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the NEXT fragment's read, then this one's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
         } else {
             // cross-check path: the same dot products as explicit fmaf chains on the vector ALU.
             // Lane (l31,h) needs x[row(r,h)][d] for every d: fetched from the lanes that hold it.
             const float *eb = Es + cur * 32 * EP + l31 * EP;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const float e0 = eb[2 * s], e1 = eb[2 * s + 1];
+                const float e0 = eb[s], e1 = eb[NS + s];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int src_row = (r & 3) + 8 * (r >> 2) + 4 * h;  // row inside the wave's 32
@@ -433,8 +495,8 @@ int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const 
               int64_t *idx, float *codes, float *dmin, float *part_d, int *part_i, hipStream_t s)
 {
     constexpr int XC = (DP < 64) ? DP : 64;
-    const size_t lds_e = (size_t)2 * 32 * (DP + 1) * sizeof(float);
-    const size_t lds_x = (size_t)128 * (XC + 1) * sizeof(float);
+    const size_t lds_e = (size_t)2 * 32 * (DP + 4) * sizeof(float);
+    const size_t lds_x = (size_t)128 * (XC + 4) * sizeof(float);
     const size_t lds = lds_e > lds_x ? lds_e : lds_x;
     const int64_t nb = nsg_cdiv(N, 128);
     if (nb > 0x7fffffff) return nsg_fail(NSG_E_UNSUPPORTED, "vq_forward: too many rows");
@@ -444,7 +506,7 @@ int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const 
                                              reinterpret_cast<const void *>(&vq_forward_kernel<DP, false>)}, lds, "vq_forward");
         if (rc != NSG_OK) return rc;
     }
-    const int S = part_d ? nsg_vq_slices(N, K) : 1;
+    const int S = part_d ? nsg_vq_slices(N, D, K) : 1;
     const int tps = (int)nsg_cdiv(nsg_cdiv(K, 32), S);
     if (mfma)
         hipLaunchKernelGGL((vq_forward_kernel<DP, true>), dim3((unsigned)nb, (unsigned)S), dim3(256), lds, s, x, e, x2, c2, N, D, K, idx, codes, dmin, tps, part_d, part_i);
@@ -457,8 +519,9 @@ int launch_vq(bool mfma, const float *x, const float *e, const float *x2, const 
 
 }  // namespace
 
-int nsg_vq_slices(int64_t N, int K)
+int nsg_vq_slices(int64_t N, int D, int K)
 {
+    const int slots = NSG_SEARCH_CUS * (D > 128 ? 1 : 2);
     const int64_t nb = nsg_cdiv(N, 128);
     if (nb <= 0) return 1;
     int best = 1;
@@ -466,15 +529,15 @@ int nsg_vq_slices(int64_t N, int K)
     for (int S = 1; S <= 8; S *= 2) {
         if (S > 1 && nsg_cdiv(K, 32) / S < 16) break;                       // a slice keeps at least 16 code tiles (a block's fixed costs)
         const int64_t units = nb * S;
-        const double eff = (double)units / (double)(nsg_cdiv(units, NSG_SEARCH_SLOTS) * NSG_SEARCH_SLOTS);
+        const double eff = (double)units / (double)(nsg_cdiv(units, slots) * slots);
         if (eff > best_eff * 1.05) { best_eff = eff; best = S; }            // more slices only for a real gain (they cost a combine pass)
     }
     return best;
 }
 
-size_t nsg_vq_slice_bytes(int64_t N, int K)
+size_t nsg_vq_slice_bytes(int64_t N, int D, int K)
 {
-    const int S = nsg_vq_slices(N, K);
+    const int S = nsg_vq_slices(N, D, K);
     return S > 1 ? 2 * nsg_align_up((size_t)S * (size_t)N * sizeof(float), 256) : 0;
 }
 
@@ -490,9 +553,8 @@ extern "C" {
 
 size_t nsg_vq_workspace_bytes(int64_t N, int32_t D, int32_t K)
 {
-    (void)D;
     if (N < 0 || K < 0) return 0;
-    return nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256) + nsg_vq_slice_bytes(N, K);
+    return nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256) + nsg_vq_slice_bytes(N, D, K);
 }
 
 int nsg_rowsumsq(const float *v, int64_t rows, int32_t D, float *out, void *stream)
@@ -517,10 +579,10 @@ static int vq_forward_impl(bool mfma, const float *x, const float *e, int64_t N,
     float *c2 = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + nsg_align_up((size_t)N * sizeof(float), 256));
     float *part_d = nullptr;
     int *part_i = nullptr;
-    if (nsg_vq_slices(N, K) > 1) {
+    if (nsg_vq_slices(N, D, K) > 1) {
         char *base = reinterpret_cast<char *>(workspace) + nsg_align_up((size_t)N * sizeof(float), 256) + nsg_align_up((size_t)K * sizeof(float), 256);
         part_d = reinterpret_cast<float *>(base);
-        part_i = reinterpret_cast<int *>(base + nsg_vq_slice_bytes(N, K) / 2);
+        part_i = reinterpret_cast<int *>(base + nsg_vq_slice_bytes(N, D, K) / 2);
     }
     int rc = nsg_rowsumsq(x, N, D, x2, stream);
     if (rc) return rc;

@@ -112,8 +112,8 @@ def test_vq_full_size_properties():
 @pytest.mark.parametrize("impl", ["mfma", "bf16x3"])
 def test_vq_sliced_search_equals_the_unsplit_search(impl):
     """BASELINE configs[3]'s search (81920 rows, K = 8192, D = 256): 640 row blocks do not fill the 512 resident slots evenly,
-    so the exact (fp32) search cuts the codebook into 4 slices and a combine pass takes the first minimum over them.  The result
-    must be the unsplit search's, bit for bit: the first 65536 rows alone are 512 blocks (one slice: the unsplit kernel) and a
+    so the exact (fp32) search (one block per CU at D = 256: 640 blocks on 256 slots) cuts the codebook into slices and a combine pass takes the first minimum over them.  The result
+    must be the unsplit search's, bit for bit: the first 65536 rows alone are 512 blocks = two full rounds (one slice: the unsplit kernel) and a
     row's result does not depend on the other rows; the exact search is also held to the CPU oracle on a sample.  (The bf16x3
     search stays unsplit -- it runs at the bf16 pipe's power-limited rate already, and the three slice arguments cost it its
     third block per CU: 311 -> 391 us at K = 512; measured, reverted -- the same properties are checked on it.)"""
