@@ -32,24 +32,6 @@ namespace {
 NSG_DIAG_SWITCH(int, g_patch_gemm, 1)        // nsg_debug_set_patch_gemm: 0 sends everything back to gemm_gather.hip's kernel
 NSG_DIAG_SWITCH(int, g_patch_grid_cap, 512)  // nsg_debug_set_patch_grid: workgroups per launch (2 per CU resident: each walks tiles with a grid stride); 0 = one tile each
 
-#ifndef NSG_PATCH_DEEP
-#define NSG_PATCH_DEEP 0     // measured in the step: 936 / 943 / 931 TF with, 952 / 941 / 936 without (same box, alternating): not the limiter
-#endif
-#ifndef NSG_PATCH_PRIO
-#define NSG_PATCH_PRIO 0
-#endif
-#ifndef NSG_PATCH_STAGGER
-#define NSG_PATCH_STAGGER 0
-#endif
-#ifndef NSG_PATCH_WDEPTH
-#define NSG_PATCH_WDEPTH 0      // 1: 4-tap jobs keep two weight buffers (fragments one tap ahead, as in round 2)
-#endif
-#ifndef NSG_PATCH_EPIPF
-#define NSG_PATCH_EPIPF 1       // 0: fused operands fetched at the start of the epilogue; 1: in the job's last tap except for ADD + MASK; 2: always
-#endif
-#ifndef NSG_PATCH_PRIV
-#define NSG_PATCH_PRIV 1
-#endif
 
 // Workgroups along x for ntiles pixel tiles and ntn channel tiles (blockIdx.y): x * ntn workgroups are resident at once (two per
 // CU), each walks its channel tile's pixel tiles with a grid stride.  (Round 2 capped x alone: with C_out = 256 the 1024
@@ -99,25 +81,23 @@ struct PatchGemmParams {
 // PH x PW: patch extent in slots (6 x 34 or 5 x 33); NT: taps per job (9 or 4); ADD / MASK: the fused epilogue operands are
 // compile-time (a run-time "maybe a load" makes hipcc guard every reuse of the destination registers with a conservative
 // vmcnt that also waits for the tile's own STORES -- the epilogue then runs at store-acknowledge latency); STAMP: diagnostics.
-// DEEP: the pixel fragments are fetched TWO k-steps ahead of their MFMAs (8 fragment registers per k-step pair instead of 4):
-// a wave whose SIMD partner is in its epilogue or at a barrier then still covers the LDS latency on its own (one k-step is
-// 4 MFMAs = 128 cycles when the wave has the matrix pipe to itself, less than a loaded ds_read_b128 takes to return).
 // PRIV: the epilogue is WAVE-PRIVATE: wave w owns channels 32 w .. + 31 of all 128 pixels, so it turns its own accumulators
 // into 64-byte output segments (4 lanes x 16 bytes per pixel) through a staging region of its own -- no workgroup barrier in
-// the epilogue (the staged form has eight per tile), LDS writes / reads / stores of consecutive tile rows software-pipelined,
-// and the fused add / mask operands are fetched inside the job's LAST tap instead of at the start of the epilogue.
+// the epilogue (the staged form has eight per tile), LDS writes / reads / stores of consecutive tile rows software-pipelined.
 // Measured (same box, isolated launches on post-ReLU-like data, us): plain variants 196 / 323 / 367 wave-private against 198-202 /
 // 327 / 374 staged (3x3, 4x4-s2, transposed); with fused operands the wave-private form LOSES (3x3 add + mask 236 vs 227,
 // transposed + mask 464-475 vs 435-443: a lane's operand loads are 64-byte segments, two waves fetch every 128-byte line of
-// the operand tensors), so those variants keep the staged epilogue (NSG_PATCH_PRIV: 0 none, 1 plain variants, 2 all).
+// the operand tensors), so those variants keep the staged epilogue: PRIV = plain variants only.  (Also measured at parity and
+// removed again: pixel fragments two k-steps ahead, s_setprio / a start delay for the younger workgroup of a CU, the fused
+// operands fetched in the job's last tap -- DESIGN.md 3.1e.)
 // STATS (plain variant, wave-private epilogue): the batch statistics of the BatchNorm that follows, from the store phase -- a lane
 // keeps the same 8 channels for every piece it stores, so it carries their running sums (about a pivot: its first value) across
 // its tiles in registers; one (count, sum, M2) record per workgroup and channel tile at the end, pooled over the lanes in lane
 // order (double).  Of the values AS STORED (rounded to bf16), real pixels only.  Replaces a read pass over the conv's output.
-template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool DEEP = (NSG_PATCH_DEEP != 0),
-          bool PRIV = (NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK))), bool STATS = false>
+template <int PH, int PW, int NT, bool ADD, bool MASK, bool STAMP = false, bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void patch_gemm_kernel(const PatchGemmParams p)
 {
+    constexpr bool PRIV = !(ADD || MASK);
     constexpr int NSLOT = PH * PW;
     constexpr int NPIECE = NSLOT * 8;                       // 16-byte pieces of a patch (64 channels = 8 pieces per slot)
     constexpr int NP = (NPIECE + 255) / 256;                // pieces per thread
@@ -127,7 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     // loses the issue arbitration and runs 30 % longer) then ran no faster than two sharing the pipe -- its taps are 512 MFMA
     // cycles and the loads did not land in that time.  Now: NB weight buffers = fragments NB - 1 taps ahead; a piece is written
     // LD taps after its fetch.  The loop body is NB taps with static buffer roles (NB divides NT, LD divides NB).
-    constexpr int NB = (NSG_PATCH_WDEPTH == 1) ? (NT == 9 ? 3 : 2) : (NT == 9 ? 3 : 4);
+    constexpr int NB = (NT == 9) ? 3 : 4;
     constexpr int LD = (NT == 9) ? 3 : 2;
     static_assert(NT % NB == 0 && NB % LD == 0 && NB >= 2, "static buffer roles inside a body of NB taps");
     constexpr int NLOAD = NT - LD;                          // taps that fetch patch pieces: 0 .. NLOAD - 1
@@ -223,7 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 
     v16f acc[4];             // one 32 x 32 tile (32 channels x 32 pixels) per tile row
     v4f breg[NB][4];         // weight fragments of NB taps
-    v4f afr[DEEP ? 2 : 1][4];    // pixel fragments of one k-step (DEEP: two): each is re-read for a later k-step right after its MFMA
+    v4f afr[4];              // pixel fragments of one k-step: each is re-read for the next k-step right after its MFMA
     v4f ptmp[LD][PPT];       // patch pieces in flight: fetched in tap t (slot t % LD), written to LDS in tap t + LD
 
     // ---- job stream: (tile, job) for this workgroup, tiles bid, bid + grid, ... ----
@@ -291,32 +271,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         for (int kk = 0; kk < 4; ++kk)
             bq[kk] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + 1024 * kk), so, 0));
     };
-    auto read_a = [&](int st, int y, int buf, int q, int kk) {
-        afr[st][y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 2 * kk * PLANE + arow[y]);
+    auto read_a = [&](int y, int buf, int q, int kk) {
+        afr[y] = *reinterpret_cast<const v4f *>(smem + buf * BUF_BYTES + tap_delta(q) + 2 * kk * PLANE + arow[y]);
     };
     auto read_a_first = [&](int buf, int q) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y) read_a(0, y, buf, q, 0);
-        if constexpr (DEEP) {
-#pragma unroll
-            for (int y = 0; y < 4; ++y) read_a(1, y, buf, q, 1);
-        }
+        for (int y = 0; y < 4; ++y) read_a(y, buf, q, 0);
     };
-    // One tap.  On entry afr holds the first k-step (DEEP: the first two) of tap q; on exit of tap qn.  At the end of a job
-    // qn = q: the next patch is not visible before the job-boundary barrier, so the reads are dummies (branch-free) and
-    // run_job reads the real fragments after the barrier.
+    // One tap.  On entry afr holds the first k-step of tap q; on exit of tap qn.  At the end of a job qn = q: the next patch is
+    // not visible before the job-boundary barrier, so the reads are dummies (branch-free) and run_job reads the real fragments
+    // after the barrier.
     auto mfma_chain = [&](const v4f (&bq)[4], int buf, int q, int qn) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            constexpr int AHEAD = DEEP ? 2 : 1;
-            const int st = DEEP ? (kk & 1) : 0;
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
-                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[st][y]), acc[y], 0, 0, 0);
-                if (kk + AHEAD < 4) read_a(st, y, buf, q, kk + AHEAD);
-                else read_a(st, y, buf, qn, kk + AHEAD - 4);
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[kk]), __builtin_bit_cast(bf16x8, afr[y]), acc[y], 0, 0, 0);
+                if (kk < 3) read_a(y, buf, q, kk + 1);
+                else read_a(y, buf, qn, 0);
             }
-            // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next 3 / 7 MFMAs)
+            // pin the interleave: MFMA, then the read that refills its operand register (it lands under the next three MFMAs)
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -329,10 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(ADD ? p.epi_add : p.out), 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(MASK ? p.epi_mask : p.out), 0, (int)out_bytes, 0x00020000);
-    // fused operands fetched in the job's last tap (else at the start of the epilogue): not for the ADD + MASK variant, whose
-    // 64 operand registers on top of the tap loop's working set reach the 256-register limit of two waves per SIMD
-    constexpr bool EPI_EARLY = PRIV && (ADD || MASK) && (NSG_PATCH_EPIPF == 2 || (NSG_PATCH_EPIPF == 1 && !(ADD && MASK)));
-    // PRIV epilogue state: byte offsets of this lane's 8 output pieces (tile row y, pixel ep + 16 e2; out of range = dropped / zero)
+    // epilogue state: byte offsets of this lane's 8 output pieces (tile row y, pixel ep + 16 e2; out of range = dropped / zero)
     // and the fused operands fetched for them
     unsigned eoff[4][2];
     v4f addv[ADD ? 4 : 1][2], maskv[MASK ? 4 : 1][2];
@@ -362,16 +333,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
                 for (int e2 = 0; e2 < 2; ++e2) maskv[y][e2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (int)eoff[y][e2], 0, 0));
         }
     };
-    // LAST (compile time): the job's last tap -- it also issues the epilogue's fused-operand loads (PRIV; offsets out of
-    // range, i.e. no traffic, unless this job ends a tile: branch-free on purpose, see the epilogue's comment)
     // J (compile time): position of the tap inside the body of NB taps = its weight buffer; qb: table entry of the tap NB - 1 later
-    auto tap = [&](auto JJ, auto LAST, int buf, int t, int q, int qn, int qb) __attribute__((always_inline)) {
+    auto tap = [&](auto JJ, int buf, int t, int q, int qn, int qb) __attribute__((always_inline)) {
         constexpr int J = decltype(JJ)::value;
         const v4f (&bq)[4] = breg[J];
         load_b(breg[(J + NB - 1) % NB], qb);
         __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the loads to their first use)
         patch_traffic(std::integral_constant<int, J % LD>{}, t, buf);
-        if constexpr (decltype(LAST)::value && EPI_EARLY) epi_prefetch();
         __builtin_amdgcn_sched_barrier(0);
         mfma_chain(bq, buf, q, qn);
     };
@@ -434,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             // channels of pixel ep + 16 e2 per lane.  LDS executes one wave's instructions in order, so row y + 1 may be
             // written right after row y's reads are ISSUED: write(y + 1) and read(y + 1) run under the arithmetic and the
             // stores of row y.
-            if constexpr (!EPI_EARLY) { epi_offsets(tile, jb, true); epi_prefetch(); }      // (else: before / inside the job's taps)
+            epi_offsets(tile, jb, true);
             float *Sw = reinterpret_cast<float *>(smem + 2 * BUF_BYTES + wave * STG_BYTES);
             float *wdst = Sw + x31 * STG_PITCH + 4 * h;
             const float *rsrc = Sw + ep * STG_PITCH + 8 * eq;
@@ -503,8 +471,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     zero_acc();
     __syncthreads();
     int buf = 0;
-    // One job: NT taps from patch buffer `buf`, in bodies of NB taps; all bodies but the last in a rolled loop, the last one at
-    // a static code position (its last tap carries the epilogue's operand prefetch).
+    // One job: NT taps from patch buffer `buf`, in bodies of NB taps; all bodies but the last in a rolled loop, the last one
+    // (whose final tap has no successor inside the job) at a static code position.
     auto run_job = [&](int qbase, int qnext_base) __attribute__((always_inline)) {
         using NO = std::integral_constant<bool, false>;
         using YES = std::integral_constant<bool, true>;
@@ -513,8 +481,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
             constexpr bool LB = decltype(LASTBODY)::value;
 #define NSG_TAP(J)                                                                                                              \
             if constexpr (J < NB) {                                                                                             \
-                if constexpr (LB && J == NB - 1) tap(std::integral_constant<int, J>{}, YES{}, buf, t0 + J, qbase + t0 + J, qbase + t0 + J, tq(t0 + J + NB - 1)); \
-                else tap(std::integral_constant<int, J>{}, NO{}, buf, t0 + J, qbase + t0 + J, qbase + t0 + J + 1, tq(t0 + J + NB - 1));   \
+                constexpr int NEXT = (LB && J == NB - 1) ? 0 : 1;                                                               \
+                tap(std::integral_constant<int, J>{}, buf, t0 + J, qbase + t0 + J, qbase + t0 + J + NEXT, tq(t0 + J + NB - 1)); \
             }
             NSG_TAP(0) NSG_TAP(1) NSG_TAP(2) NSG_TAP(3)
 #undef NSG_TAP
@@ -524,21 +492,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         for (int t0 = 0; t0 < NT - NB; t0 += NB) body(t0, NO{});
         body(NT - NB, YES{});
     };
-#if NSG_PATCH_PRIO
-    // Workgroups i and i + G/2 share a CU (observed placement; speed only): one of the two gets the matrix pipe first
-    if ((int)blockIdx.x >= (G >> 1)) __builtin_amdgcn_s_setprio(NSG_PATCH_PRIO);
-#endif
-#if NSG_PATCH_STAGGER
-    // ... and / or starts a fraction of a tile late, so that one's epilogue falls beside the other's tap loops
-    if ((int)blockIdx.x >= (G >> 1))
-        for (int i = 0; i < NSG_PATCH_STAGGER * (NT == 9 ? 1 : 2); ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     if constexpr (STAMP) st_pro = now() - st_entry;
     // One job of the stream (NB divides NT: every job starts in weight buffer 0, the roles are static per code position)
     auto do_job = [&]() __attribute__((always_inline)) {
         if constexpr (STAMP) st_t = now();
         const PatchJob jb = job_entry(cur.job);
-        if constexpr (EPI_EARLY) epi_offsets(cur.tile, jb, jb.flush != 0);    // for the prefetch in the job's last tap
         advance(pre);
         patch_origin(pre);                  // its pieces are fetched inside this job's taps
         const int qbase = cur.job * NT;
@@ -613,24 +571,23 @@ int launch_patch(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
     constexpr int NSLOT = PH * PW;
     constexpr size_t BUF_BYTES = (size_t)8 * ((NSLOT + 15) / 16 * 16) * 16;
-    constexpr bool PRIV = NSG_PATCH_PRIV == 2 || (NSG_PATCH_PRIV == 1 && !(ADD || MASK));
-    constexpr bool DEEP = NSG_PATCH_DEEP != 0;
+    constexpr bool PRIV = !(ADD || MASK);
     const size_t lds = 2 * BUF_BYTES + (PRIV ? 4 * 32 * 36 * 4 : 0);     // + the four waves' private epilogue staging
     static LdsOptIn once;
     if (lds > 65536) {
-        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP, DEEP, PRIV, STATS>)}, lds, "patch_gemm");
+        const int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP, STATS>)}, lds, "patch_gemm");
         if (rc != NSG_OK) return rc;
     }
     // two workgroups per CU resident; more tiles than that are walked with a grid stride
     const int gx = patch_grid(p.ntiles, ntiles_n);
-    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP, DEEP, PRIV, STATS>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((patch_gemm_kernel<PH, PW, NT, ADD, MASK, STAMP, STATS>), dim3((unsigned)gx, (unsigned)ntiles_n), dim3(256), lds, s, p);
     return nsg_check_launch("patch_gemm");
 }
 
 template <int PH, int PW, int NT, bool STAMP>
 int launch_patch_epi(const PatchGemmParams &p, int ntiles_n, hipStream_t s)
 {
-    if constexpr (!STAMP && NSG_PATCH_PRIV != 0) {
+    if constexpr (!STAMP) {
         if (p.stats) return launch_patch<PH, PW, NT, false, false, false, true>(p, ntiles_n, s);
     }
     if (p.epi_add && p.epi_mask) return launch_patch<PH, PW, NT, true, true, STAMP>(p, ntiles_n, s);
@@ -654,7 +611,7 @@ static int patch_kind(const GatherGemmParams &g)
     if (g.in_dtype != NSG_BF16 || g.out_dtype != NSG_BF16) return -1;
     if (g.flags & (NSG_RELU_IN | NSG_TANH_OUT)) return -1;
     // BatchNorm statistics from the store phase: the plain variant's wave-private epilogue only (else gemm_gather.hip's epilogue)
-    if (g.stats && (NSG_PATCH_PRIV == 0 || g.epi_add || g.epi_mask || (g.flags & NSG_RELU_OUT) || g.stamps)) return -1;
+    if (g.stats && (g.epi_add || g.epi_mask || (g.flags & NSG_RELU_OUT) || g.stamps)) return -1;
     if (g.CI % 64 != 0 || g.CO % 128 != 0) return -1;
     const int chunks = g.CI / 64;
     int kind;
