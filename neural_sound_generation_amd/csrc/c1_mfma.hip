@@ -535,7 +535,7 @@ constexpr int MOM_BLOCKS = 1024;
 // issued three times on hi / lo bf16 splits (hi*hi + hi*lo + lo*hi: x to 2^-17).  Block = 4 waves = a 64-pixel tile.
 // partial[block][16][17]: row t = (P[t][0..15], S[t]).
 constexpr int MOM_ROW = 17;
-constexpr int MOM_GROUP = 4;         // tiles per iteration: their patch loads are in flight together (a single tile per iteration is
+constexpr int MOM_GROUP = 8;         // tiles per iteration: their patch loads are in flight together (a single tile per iteration is
                                      // one global-memory latency per 64 pixels: 69 us for the 2.6 M pixels of the headline shape)
 __global__ __launch_bounds__(256) void c1_tap_moments_kernel(const float *__restrict__ img, float *__restrict__ partial, const C1Geom g)
 {
@@ -685,16 +685,34 @@ __global__ __launch_bounds__(64) void c1_stats_from_moments_kernel(const double 
 }
 
 // backward in ONE pass over dy: per block sums[2][C] = (sum g, invstd * sum g (h - mean)) and partial[c][17] = G^T (tap sums of
-// x g; entry 16 unused), g = dy where the ReLU passed (exact in bf16; the patch operand is rounded to bf16 as in every bf16 weight gradient).
+// x g; entry 16 unused), g = dy where the ReLU passed (exact in bf16).
+//
+// The vector ALU was this pass's bound (58 % busy, 3.1 TB/s: every wave split the same patch values into bf16 pairs, packed the
+// same tap operands and carried two running sums per element), so everything that does not depend on the channel is now done
+// ONCE per tile, by the thread that fetched it, on the way into LDS -- thread (pixel j, tap row ty) holds img[2ly-1+ty][2j-1 .. 2j+2]
+// and writes, as (hi, lo) bf16 splits, the conv's A operand [pixel][tap] and its transpose [tap][pixel] for the weight-gradient
+// MFMA -- and both sums come out of the matrix pipe: row 16 of the transposed operand is ones, so G[16][c] = sum g, and
+//   sum_p g (h - mean) = sum_t w[c][t] G[t][c] + (bias - mean) G[16][c]      (h = bias + sum_t w_t x_t, all linear in x g)
+// with G from BOTH halves of the split (x to ~2^-17: the weight gradient is now that exact, too).  Per element the ALU is left
+// with the ReLU decision (the forward's fma) and a select on the raw bf16 bits.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) void c1m_bwd_onepass_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void c1m_bwd_onepass_kernel(
     const float *__restrict__ img, const float *__restrict__ w, const float *__restrict__ bias, const bf16_t *__restrict__ dy,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ sums, float *__restrict__ partial, const C1Geom g)
 {
     constexpr int NT = 64 * NW, C = 32 * NW;
-    __shared__ __attribute__((aligned(16))) float patch[2][4 * PP];
-    __shared__ __attribute__((aligned(16))) bf16_t gbuf[2][TW * gpitch(C)];
+    constexpr int AP = 16;              // bf16 per pixel row of the conv operand (its 16 taps)
+    constexpr int QP = TW + 4;          // bf16 per tap row of the transposed operand (136 bytes: tap rows land 34 banks apart)
+    constexpr int NJ = (4 * TW + NT - 1) / NT;      // (pixel, tap row) pairs per thread
+    struct Operands {
+        bf16_t ah[TW * AP], al[TW * AP];            // conv A operand: [pixel][tap], hi and lo halves of the split
+        bf16_t ph[17 * QP], pl[16 * QP];            // its transpose [tap][pixel]; ph row 16 = 1.0
+    };
+    // ONE buffer each: the next tile waits in registers while this one is worked on, so a second LDS copy would only cost
+    // residency -- and this pass is bound by the bytes its CU has in flight (four blocks per CU: 4.7 TB/s; three: 3.2)
+    __shared__ __attribute__((aligned(16))) Operands ops;
+    __shared__ __attribute__((aligned(16))) bf16_t gbuf[TW * gpitch(C)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, hb = lane >> 5, c = 32 * wave + n;
     bf16x8 whi, wlo;
@@ -703,82 +721,133 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3))) vo
     const float mu = mean[c], is = invstd[c];
     const float fs = is * gamma[c];
     const float off = __builtin_fmaf(-mu, fs, beta[c]);
-    const unsigned tap_mask = n < 16 ? 0xffffffffu : 0u;
-    const int tap_off = ((n >> 2) & 3) * PP + (n & 3);
-    float s1 = 0.f, s2 = 0.f;
+    const int prow = n < 16 ? n : 16;                       // the lane's row of the transposed operand (rows above 16 are zero)
+    const unsigned pmask = n <= 16 ? 0xffffffffu : 0u;
     v16f dwacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+    for (int i = tid; i < TW; i += NT) ops.ph[16 * QP + i] = 0x3f80;        // the row of ones (never rewritten)
 
-    int buf = 0;
-    float pr[PatchRegs<NT>::N];
+    // the thread's (pixel, tap row) pairs of a tile: four image values each
+    auto taps_load = [&](float (&v)[NJ][4], int b, int ly, int ox0) {
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int e = tid + NT * q, j = e >> 2, ty = e & 3;
+            const int y = 2 * ly - 1 + ty, x0 = 2 * (ox0 + j) - 1;
+            const bool rowok = (e < 4 * TW) & (y >= 0) & (y < g.HH);
+            const float *src = img + ((size_t)b * g.HH + (rowok ? y : 0)) * g.WW;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k;
+                const bool ok = rowok & (x >= 0) & (x < g.WW);
+                const float t = src[ok ? x : 0];            // clamped, unconditional
+                v[q][k] = ok ? t : 0.f;
+            }
+        }
+    };
+    auto taps_store = [&](Operands &o, const float (&v)[NJ][4]) {
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            const int e = tid + NT * q, j = e >> 2, ty = e & 3;
+            if (NJ * NT != 4 * TW && e >= 4 * TW) break;
+            const unsigned h01 = pack_bf16(v[q][0], v[q][1]), h23 = pack_bf16(v[q][2], v[q][3]);
+            const unsigned l01 = pack_bf16(v[q][0] - nsg_bitsf(h01 << 16), v[q][1] - nsg_bitsf(h01 & 0xffff0000u));
+            const unsigned l23 = pack_bf16(v[q][2] - nsg_bitsf(h23 << 16), v[q][3] - nsg_bitsf(h23 & 0xffff0000u));
+            *reinterpret_cast<v2u *>(o.ah + j * AP + 4 * ty) = v2u{h01, h23};
+            *reinterpret_cast<v2u *>(o.al + j * AP + 4 * ty) = v2u{l01, l23};
+            bf16_t *th = o.ph + (4 * ty) * QP + j, *tl = o.pl + (4 * ty) * QP + j;
+            th[0] = (bf16_t)h01; th[QP] = (bf16_t)(h01 >> 16); th[2 * QP] = (bf16_t)h23; th[3 * QP] = (bf16_t)(h23 >> 16);
+            tl[0] = (bf16_t)l01; tl[QP] = (bf16_t)(l01 >> 16); tl[2 * QP] = (bf16_t)l23; tl[3 * QP] = (bf16_t)(l23 >> 16);
+        }
+    };
+
+    float tv[NJ][4];
     v4f gr[4];
     if ((int)blockIdx.x < g.ntiles) {
         int b, ly, ox0;
         tile_coords(g, blockIdx.x, b, ly, ox0);
-        patch_load<NT>(pr, img, g, b, ly, ox0, tid);
+        taps_load(tv, b, ly, ox0);
         gtile_load<NW>(gr, dy, g, b, ly, ox0, min(TW, g.LW - ox0), tid);
-        patch_store<NT>(patch[0], pr, tid);
-        gtile_to_lds<NW>(gbuf[0], gr, tid);
+        taps_store(ops, tv);
+        gtile_to_lds<NW>(gbuf, gr, tid);
     }
     __syncthreads();
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x, buf ^= 1) {
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         int b, ly, ox0;
         tile_coords(g, tile, b, ly, ox0);
         const int nxt = tile + gridDim.x;
         if (nxt < g.ntiles) {
             int nb, nly, nox0;
             tile_coords(g, nxt, nb, nly, nox0);
-            patch_load<NT>(pr, img, g, nb, nly, nox0, tid);
+            taps_load(tv, nb, nly, nox0);
             gtile_load<NW>(gr, dy, g, nb, nly, nox0, min(TW, g.LW - nox0), tid);
         }
         const int npx = min(TW, g.LW - ox0);
+        const Operands &o = ops;
         auto body = [&](auto FULL) {
-#pragma unroll
+#pragma unroll 1
             for (int mb = 0; mb < 2; ++mb) {
                 if (!decltype(FULL)::value && 32 * mb >= npx) break;
-                const v16f h = conv_block(patch[buf], mb, lane, whi, wlo, bs);
-                float d[16];
+                const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(o.ah + (32 * mb + n) * AP + 8 * hb);
+                const bf16x8 alo = *reinterpret_cast<const bf16x8 *>(o.al + (32 * mb + n) * AP + 8 * hb);
+                v16f h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[r] = 0.f;
+                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, whi, h, 0, 0, 0);       // conv_block's sequence: the forward's h, bit for bit
+                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wlo, h, 0, 0, 0);
+                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, whi, h, 0, 0, 0);
+                unsigned d[16];         // g as raw bf16 bits
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = 32 * mb + acc_pixel(r, hb);
-                    const float gv = nsg_bf2f(gbuf[buf][j * gpitch(C) + c]);
-                    bool pass = __builtin_fmaf(h[r], fs, off) > 0.f;
+                    const unsigned gv = gbuf[j * gpitch(C) + c];
+                    bool pass = __builtin_fmaf(h[r] + bs, fs, off) > 0.f;
                     if (!decltype(FULL)::value) pass = pass & (j < npx);
-                    d[r] = pass ? gv : 0.f;
-                    s1 += d[r];
-                    s2 = __builtin_fmaf(d[r], h[r] - mu, s2);
+                    d[r] = pass ? gv : 0u;
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    v4u db, pa;
+                    // k = 0 .. 7 of this half: pixels 16 s + 4 hb + {0 .. 3} and 16 s + 8 + 4 hb + {0 .. 3} of the block (acc_pixel)
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const int px = 32 * mb + 16 * s + 4 * hb;
+                    const v2u h0 = *reinterpret_cast<const v2u *>(o.ph + prow * QP + px), h1 = *reinterpret_cast<const v2u *>(o.ph + prow * QP + px + 8);
+                    const v2u l0 = *reinterpret_cast<const v2u *>(o.pl + (prow & 15) * QP + px), l1 = *reinterpret_cast<const v2u *>(o.pl + (prow & 15) * QP + px + 8);
+                    const unsigned lmask = n < 16 ? 0xffffffffu : 0u;
+                    const v4u pah = {h0.x & pmask, h0.y & pmask, h1.x & pmask, h1.y & pmask};
+                    const v4u pal = {l0.x & lmask, l0.y & lmask, l1.x & lmask, l1.y & lmask};
+                    v4u db;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        db[i] = pack_bf16(d[8 * s + 2 * i], d[8 * s + 2 * i + 1]);      // exact: g is a bf16 value or zero
-                        const int j0 = 32 * mb + acc_pixel(8 * s + 2 * i, hb), j1 = 32 * mb + acc_pixel(8 * s + 2 * i + 1, hb);
-                        pa[i] = pack_bf16(patch[buf][tap_off + 2 * j0], patch[buf][tap_off + 2 * j1]) & tap_mask;
-                    }
-                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, db), dwacc, 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) db[i] = d[8 * s + 2 * i] | (d[8 * s + 2 * i + 1] << 16);
+                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pal), __builtin_bit_cast(bf16x8, db), dwacc, 0, 0, 0);
+                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pah), __builtin_bit_cast(bf16x8, db), dwacc, 0, 0, 0);
                 }
             }
         };
         if (npx == TW) body(std::true_type{}); else body(std::false_type{});
+        __syncthreads();                    // everyone has read this tile
         if (nxt < g.ntiles) {
-            patch_store<NT>(patch[buf ^ 1], pr, tid);
-            gtile_to_lds<NW>(gbuf[buf ^ 1], gr, tid);
+            taps_store(ops, tv);
+            gtile_to_lds<NW>(gbuf, gr, tid);
         }
         __syncthreads();
     }
+    // rows of dwacc in this lane: taps acc_pixel(r, hb) for r < 8; row 16 (the ones) is r = 8 of half 0
     float *dst = partial + ((size_t)blockIdx.x * C + c) * 17;
+    float wg = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dst[acc_pixel(r, hb)] = dwacc[r];
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    for (int r = 0; r < 8; ++r) {
+        const int t = acc_pixel(r, hb);
+        dst[t] = dwacc[r];
+        wg = __builtin_fmaf(w[(size_t)c * 16 + t], dwacc[r], wg);
+    }
+    wg += __shfl_xor(wg, 32, 64);
     if (hb == 0) {
+        const float s1 = dwacc[8];
         dst[16] = 0.f;
         float *sd = sums + (size_t)blockIdx.x * 2 * C;
         sd[c] = s1;
-        sd[C + c] = s2 * is;
+        sd[C + c] = __builtin_fmaf(bs - mu, s1, wg) * is;
     }
 }
 

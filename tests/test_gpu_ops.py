@@ -682,7 +682,7 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
 
     if bf and ops.bn_relu_c1convt_supported(torch.bfloat16, C):
         # the bf16 layer works from the image's tap moments (statistics without a pass over h, backward in one pass over dy):
-        # against the two-pass forms of the same kernels (nsg_debug_set_c1_moments(0)): statistics to 1e-5, weight gradient to 1e-2
+        # against the two-pass forms of the same kernels (nsg_debug_set_c1_moments(0)): statistics to 1e-5, weight gradient to 2e-2
         # (the two-pass weight gradient rounds dh to bf16, the one-pass form multiplies the exact bf16 dy)
         from neural_sound_generation_amd import _lib
         with _lib.use_diag() as lib:        # the diagnostics build carries the switch; the product library has only the one-pass form
@@ -696,7 +696,7 @@ def test_c1conv_bn_relu_fused_layer(B, H, W, C, bf):
         np.testing.assert_allclose(invstd.cpu().numpy(), invstd2.cpu().numpy(), rtol=1e-5)             #  in the two-pass form)
         _close(dgm.cpu(), dgm2p.cpu(), tol=1e-5, what="one-pass dgamma vs two-pass")
         _close(dbt.cpu(), dbt2p.cpu(), tol=1e-5, what="one-pass dbeta vs two-pass")
-        _close(dw.cpu(), dw2p.cpu(), tol=1e-2, what="one-pass dw vs two-pass")
+        _close(dw.cpu(), dw2p.cpu(), tol=2e-2, what="one-pass dw vs two-pass")
 
     # eval mode: statistics are inputs
     em, ei = ops.bn_eval_stats(rmg, rvg)
