@@ -287,3 +287,26 @@ def write_synthetic_data_root(data_root: str, n_utts: int = 12, min_frames: int 
         lines.append("|".join(fields))
     with open(join(data_root, "train.txt"), "w", encoding="utf-8") as f:
         f.write("\n".join(lines) + "\n")
+
+
+def synthetic_mel_batch(B: int, T: int, generator: torch.Generator, device, n_mels: int = 80) -> torch.Tensor:
+    """(B, 1, n_mels, T) float32 in [0, 1] with the texture of a normalised mel spectrogram (the range of
+    src/audio_tacotron.py:228-234): a few harmonic ridges per clip whose pitch and energy drift over the frames, a little noise.
+    For convergence checks and demos without a corpus -- white noise (bench.py's timing input) cannot be
+    reconstructed, so a loss on it says nothing.  No reference counterpart."""
+    t = torch.linspace(0, 1, T, device=device).view(1, 1, T)
+    h = torch.linspace(0, 1, n_mels, device=device).view(1, n_mels, 1)
+    x = torch.zeros(B, n_mels, T, device=device)
+
+    def u():
+        return torch.rand(B, 1, 1, generator=generator, device=device)
+
+    for _ in range(4):
+        f0, drift, rate, phase = u() * 0.5 + 0.1, (u() - 0.5) * 0.3, u() * 6 + 1, u() * 6.28
+        centre = f0 + drift * torch.sin(rate * 6.28 * t + phase)
+        width = u() * 0.04 + 0.02
+        energy = 0.5 + 0.5 * torch.sin(u() * 20 * t + phase)
+        x = x + energy * torch.exp(-((h - centre) / width) ** 2)
+    x = x + 0.05 * torch.randn(B, n_mels, T, generator=generator, device=device)
+    return torch.sigmoid(3.0 * (x - 0.5)).unsqueeze(1).contiguous()
+
