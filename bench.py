@@ -263,12 +263,13 @@ def main():
     if not args.no_other_configs and world == 1 and (D, K) == (128, 512):
         # the other single-GPU configurations of BASELINE.json, short runs:
         #   configs[2]  speaker-conditioned decoder (7 speakers, hparams.py:84), K = 512, D = 128, same batch as the headline
-        #   configs[3]  the large codebook (K = 8192, D = 256), 16 clips: stresses the distance contraction + argmin; both
-        #               searches: the bit-exact fp32 one (parity mode) and the bf16x3 one (bf16 mode)
+        #   configs[3]  the large codebook (K = 8192, D = 256), 32 clips (the best of SURVEY.md 8d's {8, 16, 32}: scripts/batch_sweep_c3.sh):
+        #               stresses the distance contraction + argmin; both searches: the bit-exact fp32 one (parity mode) and the
+        #               bf16x3 one (bf16 mode)
         #   configs[4]  its per-GPU share on ONE GPU: 256 clips (the 8-GPU curve itself is the driver's to measure)
         other_configs = []
-        plan = [("configs[2] 7 speakers", "bf16", 128, 512, B, 7, 5), ("configs[3] D=256 K=8192", "bf16", 256, 8192, 16, None, 5),
-                ("configs[3] D=256 K=8192", "f32", 256, 8192, 16, None, 5), ("configs[4] share: 256 clips", "bf16", 128, 512, 256, None, 4)]
+        plan = [("configs[2] 7 speakers", "bf16", 128, 512, B, 7, 5), ("configs[3] D=256 K=8192", "bf16", 256, 8192, 32, None, 5),
+                ("configs[3] D=256 K=8192", "f32", 256, 8192, 32, None, 4), ("configs[4] share: 256 clips", "bf16", 128, 512, 256, None, 4)]
         for tag, od, d_, k_, b_, spk, st in plan:
             o = run_mode(od, st, 2, False, D=d_, K=k_, B=b_, census_steps=2, n_speakers=spk)
             peak = PEAK_BF16_MFMA_TFLOPS if od == "bf16" else PEAK_F32_MFMA_TFLOPS
