@@ -47,9 +47,9 @@ def host_threads() -> int:
     return max(1, min(n, int(os.environ.get("NSG_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(D, K, T, threads, batch=4, warmup=1, steps=3):
+def cpu_baseline(D, K, T, threads, batch=4, warmup=1, steps=10):
     """The oracle (CPU restatement of the reference path, oracle/vqvae_oracle.py) timed on the host
-    cores: a bounded sample (batch clips x `steps` steps) of the same workload."""
+    cores: a bounded sample (batch clips x `steps` steps, about 10 s of CPU work) of the same workload."""
     from oracle import vqvae_oracle as O
     from neural_sound_generation_amd import models as M
     torch.set_num_threads(threads)
@@ -308,7 +308,7 @@ def main():
             threads = host_threads()
             v, dt = cpu_baseline(D, K, T, threads)
             cpu = {"value": round(v, 1), "unit": "mel-frames/s", "cores": threads, "kind": "port",
-                   "sample": f"oracle train_step, 4 clips x 80x{T}, 1 warm-up + 3 timed steps ({dt * 1e3:.0f} ms/step)"}
+                   "sample": f"oracle train_step, 4 clips x 80x{T}, 1 warm-up + 10 timed steps ({dt * 1e3:.0f} ms/step)"}
         if tables:
             write_kernel_tables(tables)
         print(build_line(value=value, ms_per_step=ms_per_step, world=world, steps=args.steps, warmup=args.warmup, dtype=args.dtype,
