@@ -38,7 +38,7 @@ extern "C" {
 #define NSG_API
 #endif
 
-#define NSG_VERSION 101 /* bumped on ANY change of an existing entry point's signature; _lib.py refuses a library of another version */
+#define NSG_VERSION 102 /* bumped on ANY change of an existing entry point's signature; _lib.py refuses a library of another version */
 
 enum {
     NSG_OK = 0,
@@ -454,6 +454,17 @@ NSG_API int nsg_vq_losses(const float *z, const float *q, int64_t n, float dz_sc
 NSG_API int nsg_vq_losses_indexed(const float *z, const float *codebook, const int64_t *idx, int64_t N, int32_t D, int32_t K,
                                   float dz_scale, const void *dz_add, float *loss_out, void *dz, int32_t grad_dtype,
                                   void *workspace, size_t workspace_bytes, void *stream);
+/* The same when dz is the incoming gradient of a BatchNorm whose input is bn_x [N][D] of grad_dtype (the encoder's last
+ * ResBlock ends in one, src/models.py:154): that BatchNorm's backward sums over the dz values as stored -- bn_dbeta[d] = sum_n
+ * dz[n][d], bn_dgamma[d] = sum_n dz[n][d] * (bn_x[n][d] - bn_mean[d]) * bn_invstd[d], what nsg_bn_backward_sums(bn_x, dz)
+ * returns, bit for bit when grad_dtype is NSG_BF16 (the same slabs, the same order) -- are formed while dz is written, instead of
+ * a pass that reads dz and bn_x back.  D: a multiple of 8 up to 2048 (nsg_vq_losses_indexed_bn_supported); dz must not be NULL. */
+NSG_API int32_t nsg_vq_losses_indexed_bn_supported(int32_t D);
+NSG_API size_t nsg_vq_losses_indexed_bn_workspace_bytes(int64_t N, int32_t D);
+NSG_API int nsg_vq_losses_indexed_bn(const float *z, const float *codebook, const int64_t *idx, int64_t N, int32_t D, int32_t K,
+                                     float dz_scale, const void *dz_add, float *loss_out, void *dz, int32_t grad_dtype,
+                                     const void *bn_x, const float *bn_mean, const float *bn_invstd, float *bn_dgamma,
+                                     float *bn_dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* torch.optim.Adam step (src/main.py:124 defaults, no weight decay, no amsgrad) over one flat
  * fp32 buffer.  g is multiplied by grad_scale first (1/world_size after a sum all-reduce).

@@ -18,7 +18,7 @@ NSG_OUT_F32 = 8
 NSG_RELU_OUT = 16
 NSG_F32 = 0
 NSG_BF16 = 1
-NSG_VERSION = 101      # include/nsg.h NSG_VERSION this binding was written against (bumped on ANY signature change)
+NSG_VERSION = 102      # include/nsg.h NSG_VERSION this binding was written against (bumped on ANY signature change)
 
 
 class ConvDesc(Structure):
@@ -103,6 +103,9 @@ _SIGS = {
     "nsg_reduce_workspace_bytes": (c_size_t, [c_int64]),
     "nsg_mse_padded": (None, [_P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, c_size_t, _P]),
     "nsg_vq_losses_indexed": (None, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, c_int32, _P, c_size_t, _P]),
+    "nsg_vq_losses_indexed_bn_supported": (c_int32, [c_int32]),
+    "nsg_vq_losses_indexed_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "nsg_vq_losses_indexed_bn": (None, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "nsg_vq_losses": (None, [_P, _P, c_int64, c_float, c_float, _P, _P, _P, _P, c_int32, _P, c_size_t, _P]),
     "nsg_adam_step": (None, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, _P]),
     "nsg_gated_activation_forward": (None, [_P, _P, _P, c_int64, c_int32, c_int64, _P]),

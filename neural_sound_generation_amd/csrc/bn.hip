@@ -548,6 +548,15 @@ size_t nsg_bn_tiles_bytes(int64_t ntiles, int C)
     return nsg_align_up((size_t)ntiles * 3 * C, 64) * sizeof(float) + (size_t)TILE_CHUNKS * 3 * C * sizeof(double) + 256;
 }
 
+// the slab structure of nsg_bn_backward_sums over M rows: a producer of dy that forms the same sums itself (elementwise.hip:
+// nsg_vq_losses_indexed_bn) walks the rows the same way, so its results are those of the separate pass, bit for bit
+void nsg_bn_slab_geom(int64_t M, int *nslab, int *rows)
+{
+    const SlabGeom g = slab_geom(M);
+    *nslab = g.nslab;
+    *rows = g.rows;
+}
+
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s)
 {
     if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "bn_bwd_final: %d slabs / %d channels not supported", nslab, C);

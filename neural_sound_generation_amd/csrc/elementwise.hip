@@ -213,17 +213,36 @@ __global__ __launch_bounds__(256) void vq_losses_kernel(const float *__restrict_
 
 // The same loss and encoder-side gradient with q given as (codebook, indices): q[row] = e[idx[row]] is read from the
 // L2-resident codebook instead of a materialised [N][D] tensor.  D % 8 == 0; a thread takes 8 channels of one row.
-template <typename TG>
+template <typename T> __device__ __forceinline__ float round_as(float v);       // v as it reads back after a store as T
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return nsg_bf2f(nsg_f2bf(v)); }
+
+// Slab-structured exactly as bn_bwd_partial_kernel (bn.hip): block = one slab of slab_rows rows, thread (cg = tid % (D / 8),
+// rg = tid / (D / 8)) takes channels 8 cg .. + 7 of rows r0 + rg, + 256 / (D / 8), ...  (threads past the last whole row group idle).
+// BN: dz is the incoming gradient of a BatchNorm whose input is bn_x (the encoder's last ResBlock, src/models.py:154): the two
+// sums of that BatchNorm's backward -- bn_partial[slab][2][D] = (sum dz, sum dz * xhat) of the values AS STORED -- are formed
+// while dz is written, with bn_bwd_partial_kernel's expressions in its order: for bf16 gradients (8 channels per thread there
+// too) the finished sums equal those of the separate pass over (bn_x, dz) bit for bit.
+template <typename TG, bool BN>
 __global__ __launch_bounds__(256) void vq_losses_indexed_kernel(const float *__restrict__ z, const float *__restrict__ e,
                                                                 const int64_t *__restrict__ idx, int64_t N, int D, int K, float zscale,
-                                                                const TG *__restrict__ dz_add, TG *__restrict__ dz, double *partial)
+                                                                const TG *__restrict__ dz_add, TG *__restrict__ dz, double *partial,
+                                                                int slab_rows, const TG *__restrict__ bn_x,
+                                                                const float *__restrict__ bn_mean, const float *__restrict__ bn_invstd,
+                                                                float *__restrict__ bn_partial)
 {
     const int D8 = D >> 3;
-    const int64_t nv = N * D8;
+    const int rgroups = 256 / D8;
+    const int cg = threadIdx.x % D8, rg = threadIdx.x / D8;
+    const int d8 = cg * 8;
+    const int64_t r0 = (int64_t)blockIdx.x * slab_rows;
+    const int64_t r1 = min(N, r0 + (int64_t)slab_rows);
     double acc = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / D8;
-        const int d8 = (int)(i - row * D8) * 8;
+    float s1[8], s2[8], mu[8], is[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; mu[c] = BN ? bn_mean[d8 + c] : 0.f; is[c] = BN ? bn_invstd[d8 + c] : 0.f; }
+    for (int64_t row = r0 + rg; row < r1 && rg < rgroups; row += rgroups) {
+        const int64_t i = row * D8 + cg;
         int64_t k = idx[row];
         k = k < 0 ? 0 : (k >= K ? K - 1 : k);                 // (validated indices; clamped so a bad one cannot fault)
         float zv[8], qv[8], g[8];
@@ -243,9 +262,37 @@ __global__ __launch_bounds__(256) void vq_losses_indexed_kernel(const float *__r
                 for (int c = 0; c < 8; ++c) g[c] += av[c];
             }
             stw<TG, 8>(dz + i * 8, g);
+            if constexpr (BN) {
+                float xv[8];
+                ldw<TG, 8>(bn_x + i * 8, xv);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float gs = round_as<TG>(g[c]);
+                    s1[c] += gs;
+                    s2[c] += gs * ((xv[c] - mu[c]) * is[c]);
+                }
+            }
         }
     }
     block_sum_store(acc, partial);
+    if constexpr (BN) {
+        __shared__ float red[2 * 256 * 8];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (rg < rgroups) { red[(rg * D8 + cg) * 8 + c] = s1[c]; red[256 * 8 + (rg * D8 + cg) * 8 + c] = s2[c]; }
+        __syncthreads();
+        if ((int)threadIdx.x < D8) {
+            float *dst = bn_partial + (size_t)blockIdx.x * 2 * D;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int gq = 0; gq < rgroups; ++gq) { t1 += red[(gq * D8 + threadIdx.x) * 8 + c]; t2 += red[256 * 8 + (gq * D8 + threadIdx.x) * 8 + c]; }
+                dst[threadIdx.x * 8 + c] = t1;
+                dst[D + threadIdx.x * 8 + c] = t2;
+            }
+        }
+    }
 }
 
 template <int V>
@@ -527,7 +574,7 @@ int nsg_vq_losses_indexed(const float *z, const float *codebook, const int64_t *
                           void *stream)
 {
     NSG_REQUIRE(z && codebook && idx && loss_out && N > 0 && D > 0 && K > 0, NSG_E_INVALID, "nsg_vq_losses_indexed: bad argument");
-    NSG_REQUIRE(D % 8 == 0, NSG_E_UNSUPPORTED, "nsg_vq_losses_indexed: D=%d must be a multiple of 8", D);
+    NSG_REQUIRE(D % 8 == 0 && D <= 2048, NSG_E_UNSUPPORTED, "nsg_vq_losses_indexed: D=%d must be a multiple of 8 up to 2048", D);
     NSG_REQUIRE(grad_dtype == NSG_F32 || grad_dtype == NSG_BF16, NSG_E_INVALID, "nsg_vq_losses_indexed: grad_dtype must be NSG_F32 or NSG_BF16");
     NSG_REQUIRE(nsg_aligned16(z) && nsg_aligned16(codebook) && (!dz || nsg_aligned16(dz)) && (!dz_add || nsg_aligned16(dz_add)), NSG_E_INVALID,
                 "nsg_vq_losses_indexed: pointers must be 16-byte aligned");
@@ -536,14 +583,56 @@ int nsg_vq_losses_indexed(const float *z, const float *codebook, const int64_t *
     hipStream_t s = (hipStream_t)stream;
     double *partial = reinterpret_cast<double *>(workspace);
     const float zs = dz_scale * 2.0f / (float)n;
-    int nb = ew_blocks(n / 8);
-    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    int nb, rows;
+    nsg_bn_slab_geom(N, &nb, &rows);
+    static_assert(RED_BLOCKS >= 1024, "one loss partial per slab");
     if (grad_dtype == NSG_BF16)
-        hipLaunchKernelGGL((vq_losses_indexed_kernel<bf16_t>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const bf16_t *)dz_add, (bf16_t *)dz, partial);
+        hipLaunchKernelGGL((vq_losses_indexed_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const bf16_t *)dz_add, (bf16_t *)dz, partial,
+                           rows, (const bf16_t *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     else
-        hipLaunchKernelGGL((vq_losses_indexed_kernel<float>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const float *)dz_add, (float *)dz, partial);
+        hipLaunchKernelGGL((vq_losses_indexed_kernel<float, false>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const float *)dz_add, (float *)dz, partial,
+                           rows, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, s, partial, nb, (double)n, loss_out);
     return nsg_check_launch("vq_losses_indexed");
+}
+
+int32_t nsg_vq_losses_indexed_bn_supported(int32_t D) { return D >= 8 && D % 8 == 0 && D <= 2048 ? 1 : 0; }
+
+size_t nsg_vq_losses_indexed_bn_workspace_bytes(int64_t N, int32_t D)
+{
+    if (N <= 0 || D <= 0) return 0;
+    return nsg_align_up(nsg_reduce_workspace_bytes(N * D), 256) + (size_t)RED_BLOCKS * 2 * D * sizeof(float);
+}
+
+int nsg_vq_losses_indexed_bn(const float *z, const float *codebook, const int64_t *idx, int64_t N, int32_t D, int32_t K, float dz_scale,
+                             const void *dz_add, float *loss_out, void *dz, int32_t grad_dtype, const void *bn_x, const float *bn_mean,
+                             const float *bn_invstd, float *bn_dgamma, float *bn_dbeta, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    NSG_REQUIRE(z && codebook && idx && loss_out && dz && bn_x && bn_mean && bn_invstd && bn_dgamma && bn_dbeta && N > 0 && K > 0, NSG_E_INVALID,
+                "nsg_vq_losses_indexed_bn: bad argument");
+    NSG_REQUIRE(nsg_vq_losses_indexed_bn_supported(D), NSG_E_UNSUPPORTED, "nsg_vq_losses_indexed_bn: D=%d must be a multiple of 8 up to 2048", D);
+    NSG_REQUIRE(grad_dtype == NSG_F32 || grad_dtype == NSG_BF16, NSG_E_INVALID, "nsg_vq_losses_indexed_bn: grad_dtype must be NSG_F32 or NSG_BF16");
+    NSG_REQUIRE(nsg_aligned16(z) && nsg_aligned16(codebook) && nsg_aligned16(dz) && nsg_aligned16(bn_x) && (!dz_add || nsg_aligned16(dz_add)), NSG_E_INVALID,
+                "nsg_vq_losses_indexed_bn: pointers must be 16-byte aligned");
+    const int64_t n = N * D;
+    NSG_REQUIRE(workspace && workspace_bytes >= nsg_vq_losses_indexed_bn_workspace_bytes(N, D), NSG_E_WORKSPACE, "nsg_vq_losses_indexed_bn: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = reinterpret_cast<double *>(workspace);
+    float *bnp = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + nsg_align_up(nsg_reduce_workspace_bytes(n), 256));
+    const float zs = dz_scale * 2.0f / (float)n;
+    int nb, rows;
+    nsg_bn_slab_geom(N, &nb, &rows);
+    if (grad_dtype == NSG_BF16)
+        hipLaunchKernelGGL((vq_losses_indexed_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const bf16_t *)dz_add, (bf16_t *)dz, partial,
+                           rows, (const bf16_t *)bn_x, bn_mean, bn_invstd, bnp);
+    else
+        hipLaunchKernelGGL((vq_losses_indexed_kernel<float, true>), dim3(nb), dim3(256), 0, s, z, codebook, idx, N, D, K, zs, (const float *)dz_add, (float *)dz, partial,
+                           rows, (const float *)bn_x, bn_mean, bn_invstd, bnp);
+    hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, s, partial, nb, (double)n, loss_out);
+    int rc = nsg_check_launch("vq_losses_indexed_bn");
+    if (rc) return rc;
+    return nsg_launch_bn_bwd_final(bnp, nb, D, bn_dgamma, bn_dbeta, s);
 }
 
 int nsg_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -260,6 +260,7 @@ size_t nsg_bn_tiles_bytes(int64_t ntiles, int C);
 int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, float eps, float momentum, float *mean,
                             float *invstd, float *running_mean, float *running_var, hipStream_t s);
 // dbeta[c] = sum_s partial[s][0][c], dgamma[c] = sum_s partial[s][1][c] over nslab <= 1024 slabs of [2][C] (fixed order, double)
+void nsg_bn_slab_geom(int64_t M, int *nslab, int *rows);      // bn.hip: slabs of nsg_bn_backward_sums over M rows
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s);
 // ... and colsum[c] = sum_s colsum_partial[s][c] in the same launch
 int nsg_launch_bn_bwd_final_colsum(const float *partial, const float *colsum_partial, int nslab, int C, float *dgamma, float *dbeta,

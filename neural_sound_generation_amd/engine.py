@@ -183,9 +183,17 @@ def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_
     return y, saved
 
 
-def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=None):
+def resblock_bn2(saved):
+    """(h2, mean, invstd) of a ResBlock's closing BatchNorm from its saved forward state: for a producer of the block's incoming
+    gradient that forms that BatchNorm's backward sums itself (ops.vq_losses_indexed(bn=)); pass them on as bn2_sums=."""
+    return saved[3], saved[6], saved[7]
+
+
+def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=None, bn2_sums=None):
     """Returns (dx, grads) with grads in the order conv1.w, conv1.b, bn1.w, bn1.b, conv2.w, conv2.b, bn2.w, bn2.b.
-    gout: optional list of 8 preallocated tensors (e.g. views of a flat gradient bucket) to write into."""
+    gout: optional list of 8 preallocated tensors (e.g. views of a flat gradient bucket) to write into.
+    bn2_sums: (dgamma, dbeta) of the closing BatchNorm when whoever produced dy has formed them already (written into gout[6],
+    gout[7] if gout is given)."""
     x, h1, a1, h2, m1, i1, m2, i2, d1, d2, wd1, wd2 = saved
     o = gout if gout is not None else [None] * 8
     D = h2.shape[-1]
@@ -194,7 +202,10 @@ def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=N
     dbias2 = o[5] if o[5] is not None else torch.empty(D, dtype=torch.float32, device=h2.device)
     dbias1 = o[1] if o[1] is not None else torch.empty(D, dtype=torch.float32, device=h2.device)
     if a1 is None:      # flat-GEMM 1x1: bn2's sums, then its apply + the conv's data gradient in one pass, the weight gradient from h1
-        dg2, db2n = ops.bn_backward_sums(h2, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7])
+        if bn2_sums is not None:
+            dg2, db2n = bn2_sums
+        else:
+            dg2, db2n = ops.bn_backward_sums(h2, dy, m2, i2, P.bn2.weight, dgamma=o[6], dbeta=o[7])
         if FUSED_1X1_BWD and ops.bn_backward_conv1x1_dgrad_wgrad_supported(h2.dtype, D):     # data + weight gradient in one pass, dh2 never stored
             da1, dw2, dg1, db1n = ops.bn_backward_conv1x1_dgrad_wgrad(h2, dy, m2, i2, P.bn2.weight, dg2, db2n, P.conv2.weight,
                                                                       (h1, m1, i1, P.bn1.weight, P.bn1.bias), dh_colsum=dbias2, dw=o[4],
@@ -253,13 +264,14 @@ def encoder_forward(x, P: EncoderParams, training: bool, dtype=torch.float32, pa
     return ze, saved
 
 
-def encoder_backward(dze, saved, P: EncoderParams, gout=None):
+def encoder_backward(dze, saved, P: EncoderParams, gout=None, bn2_sums=None):
     """Gradients of every encoder parameter, in state_dict order (input gets none: it is data).
-    dze must have the encoder's compute dtype.  gout: optional list of 22 preallocated tensors to write into."""
+    dze must have the encoder's compute dtype.  gout: optional list of 22 preallocated tensors to write into.
+    bn2_sums: (dgamma, dbeta) of the last ResBlock's closing BatchNorm, when dze's producer formed them (resblock_backward)."""
     x, h0, a0, m0, i0, d0, d3, wd3, s4, s5, mom0 = saved
     dze = ops.convert(dze, a0.dtype)
     o = gout if gout is not None else [None] * 22
-    dr4, g5 = resblock_backward(dze, s5, P.res5, gout=o[14:22] if gout is not None else None)
+    dr4, g5 = resblock_backward(dze, s5, P.res5, gout=o[14:22] if gout is not None else None, bn2_sums=bn2_sums)
     de3, g4 = resblock_backward(dr4, s4, P.res4, gout=o[6:14] if gout is not None else None)
     dw3, db3 = ops.conv_wgrad(d3, a0, de3, P.conv3.weight.shape, dw=o[4], dbias=o[5])
     da0 = ops.conv_dgrad(d3, de3, wd3)

@@ -837,14 +837,35 @@ def vq_losses(z, q, dz_scale=1.0, dq_scale=1.0, dz_add=None, want_dz=True, want_
     return loss, dz, dq
 
 
-def vq_losses_indexed(z2d, codebook, idx, dz_scale=1.0, dz_add=None, want_dz=True, grad_dtype=torch.float32):
-    """vq_losses with q = codebook[idx] read from the codebook itself: returns (loss, dz).  z2d (N, D) fp32."""
+def vq_losses_indexed_bn_supported(D) -> bool:
+    return bool(_lib.query("nsg_vq_losses_indexed_bn_supported", c_int32(D)))
+
+
+def vq_losses_indexed(z2d, codebook, idx, dz_scale=1.0, dz_add=None, want_dz=True, grad_dtype=torch.float32, bn=None, dgamma=None,
+                      dbeta=None):
+    """vq_losses with q = codebook[idx] read from the codebook itself: returns (loss, dz).  z2d (N, D) fp32.
+    bn = (x, mean, invstd): dz is the incoming gradient of a BatchNorm with input x (N, D) of grad_dtype; returns
+    (loss, dz, dgamma, dbeta) with that BatchNorm's backward sums (= bn_backward_sums(x, dz, ...)) formed while dz is written."""
     _chk(z2d, "z"); _chk(codebook, "codebook"); _chk(idx, "idx", torch.int64)
     if dz_add is not None:
         _chk(dz_add, "dz_add", grad_dtype)
     N, D = z2d.shape
     loss = torch.empty(1, dtype=torch.float32, device=z2d.device)
     dz = torch.empty(z2d.shape, dtype=grad_dtype, device=z2d.device) if want_dz else None
+    if bn is not None:
+        x, mean, invstd = bn
+        _chk(x, "bn x", grad_dtype); _chk(mean, "bn mean"); _chk(invstd, "bn invstd")
+        if dz is None or x.numel() != N * D:
+            raise _lib.NsgError("vq_losses_indexed: bn= needs want_dz and a BatchNorm input of z's shape")
+        dgamma = dgamma if dgamma is not None else torch.empty(D, dtype=torch.float32, device=z2d.device)
+        dbeta = dbeta if dbeta is not None else torch.empty(D, dtype=torch.float32, device=z2d.device)
+        nb = _lib.query("nsg_vq_losses_indexed_bn_workspace_bytes", c_int64(N), c_int32(D))
+        ws = WS.get(nb, z2d.device)
+        _lib.tag("vq_losses_indexed", 0, 4.0 * N * D + 8.0 * N + dz.numel() * _es(dz) * (3 if dz_add is not None else 2))
+        _lib.call("nsg_vq_losses_indexed_bn", _p(z2d), _p(codebook), _p(idx), c_int64(N), c_int32(D), c_int32(codebook.shape[0]),
+                  c_float(dz_scale), _p(dz_add), _p(loss), _p(dz), c_int32(nsg_dtype(grad_dtype)), _p(x), _p(mean), _p(invstd), _p(dgamma),
+                  _p(dbeta), _p(ws), c_size_t(nb), _stream())
+        return loss, dz, dgamma, dbeta
     nb = _lib.query("nsg_reduce_workspace_bytes", c_int64(N * D))
     ws = WS.get(nb, z2d.device)
     _lib.tag("vq_losses_indexed", 0, 4.0 * N * D + 8.0 * N + (dz.numel() * _es(dz) * (2 if dz_add is not None else 1) if dz is not None else 0))

@@ -145,9 +145,18 @@ class FusedTrainStep:
         self._reduce_back_part()        # decoder, speaker table, EMA statistics: final from here on (no-op on one rank / in a graph)
         # loss_vq = mse(z_q, sg(z_e)) -> codebook; loss_commit = mse(z_e, sg(z_q)) -> encoder,
         # plus the straight-through gradient from the decoder               (train.py:131-134)
+        bn2_sums = None
         if lean:
-            loss_vq, dz = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
-                                                grad_dtype=self.dtype)
+            # dz is the incoming gradient of the encoder's closing BatchNorm: its backward sums are formed while dz is written
+            h2, m2, i2 = engine.resblock_bn2(es[9])
+            if h2.dtype == self.dtype and engine.FUSED_1X1 and ops.bn_relu_conv1x1_supported(self.dtype, D):
+                loss_vq, dz, dg, db = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
+                                                            grad_dtype=self.dtype, bn=(h2.view(-1, D), m2, i2), dgamma=self.g_enc[20],
+                                                            dbeta=self.g_enc[21])
+                bn2_sums = (dg, db)
+            else:
+                loss_vq, dz = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
+                                                    grad_dtype=self.dtype)
             dz = dz.view(ze.shape)
             if not self.ema:    # d loss_vq / d e_k = 2/numel * sum over the rows assigned to k of (e_k - z) = 2/numel * (n_k e_k - s_k)
                 s, n = ops.index_add_rows(idx, ze.view(-1, D), K, want_counts=True, impl=self.scatter_impl)
@@ -159,7 +168,7 @@ class FusedTrainStep:
         else:
             loss_vq, dz, dq = ops.vq_losses(ze, zq, dz_scale=self.beta, dq_scale=1.0, dz_add=dzq, grad_dtype=self.dtype)
             self._codebook_grad(idx, dq.view(-1, D), K)
-        engine.encoder_backward(dz, es, self.encP, gout=self.g_enc)
+        engine.encoder_backward(dz, es, self.encP, gout=self.g_enc, bn2_sums=bn2_sums)
         self.last_indices = idx
         return loss_recons, loss_vq, loss_vq
 

@@ -961,6 +961,38 @@ def test_vq_losses():
     np.testing.assert_allclose(dq.cpu().numpy(), gq.numpy(), rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("N,D,K,dt", [(5120, 128, 512, torch.bfloat16), (3000, 64, 128, torch.bfloat16), (700, 256, 300, torch.bfloat16),
+                                      (2048, 128, 64, torch.float32), (130000, 128, 512, torch.bfloat16), (777, 96, 40, torch.bfloat16)])
+def test_vq_losses_indexed_with_batchnorm_sums(N, D, K, dt):
+    """nsg_vq_losses_indexed_bn: the loss and dz of nsg_vq_losses_indexed bit for bit, plus the backward sums of the BatchNorm whose
+    incoming gradient dz is -- against nsg_bn_backward_sums reading the stored dz back (bit for bit for bf16 gradients: the same
+    slab walk; 2e-5 of scale for fp32 ones, whose separate pass takes 4 channels per thread), and reproducible."""
+    g = torch.Generator().manual_seed(N + D)
+    z = gpu(torch.randn(N, D, generator=g))
+    e = gpu(torch.randn(K, D, generator=g) * 0.1)
+    idx = gpu(torch.randint(0, K, (N,), generator=g))
+    add = gpu(torch.randn(N, D, generator=g) * 1e-3).to(dt)
+    x = gpu(torch.randn(N, D, generator=g) * 0.5 + 0.2).to(dt)
+    mean, invstd = gpu(torch.randn(D, generator=g) * 0.1 + 0.2), gpu(torch.rand(D, generator=g) + 1.0)
+    gamma = torch.ones(D, device=DEV)
+    assert ops.vq_losses_indexed_bn_supported(D)
+    l0, dz0 = ops.vq_losses_indexed(z, e, idx, dz_scale=0.25, dz_add=add, grad_dtype=dt)
+    l1, dz1, dg, db = ops.vq_losses_indexed(z, e, idx, dz_scale=0.25, dz_add=add, grad_dtype=dt, bn=(x, mean, invstd))
+    assert torch.equal(l0, l1) and torch.equal(dz0, dz1)
+    dg_ref, db_ref = ops.bn_backward_sums(x, dz0, mean, invstd, gamma)
+    if dt == torch.bfloat16:        # the same slabs in the same order: the separate pass's sums, bit for bit
+        assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    _close(dg.cpu(), dg_ref.cpu(), tol=2e-5, what="dgamma")
+    _close(db.cpu(), db_ref.cpu(), tol=2e-5, what="dbeta")
+    want_b = dz0.double().sum(0)
+    want_g = (dz0.double() * ((x.double() - mean.double()) * invstd.double())).sum(0)
+    _close(db.double().cpu(), want_b.cpu(), tol=2e-5, what="dbeta vs double")
+    _close(dg.double().cpu(), want_g.cpu(), tol=2e-5, what="dgamma vs double")
+    _, _, dg2, db2 = ops.vq_losses_indexed(z, e, idx, dz_scale=0.25, dz_add=add, grad_dtype=dt, bn=(x, mean, invstd))
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert ops.vq_losses_indexed_bn_supported(96) and not ops.vq_losses_indexed_bn_supported(100)
+
+
 def test_adam_matches_torch_optim():
     g = torch.Generator().manual_seed(21)
     p0 = torch.randn(5000, generator=g)
