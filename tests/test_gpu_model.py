@@ -1005,6 +1005,8 @@ def test_bf16_mode_trains_like_the_fp32_mode():
         curves[name] = torch.stack([step.step(synthetic_mel_batch(8, 256, gen, DEV))[0] for _ in range(120)]).cpu()
         assert torch.isfinite(curves[name]).all()
     f, b = curves["f32"], curves["bf16"]
+    print(f"reconstruction loss, first step / mean of the last 30: fp32 {f[0].item():.5f} / {f[-30:].mean().item():.5f}, "
+          f"bf16 {b[0].item():.5f} / {b[-30:].mean().item():.5f}")
     assert abs(b[0].item() - f[0].item()) <= 0.02 * f[0].item()
     assert f[-30:].mean() < 0.1 * f[0] and b[-30:].mean() < 0.1 * b[0], (f[0].item(), f[-30:].mean().item(), b[-30:].mean().item())
     assert abs(b[-30:].mean() - f[-30:].mean()) <= 0.15 * f[-30:].mean(), (f[-30:].mean().item(), b[-30:].mean().item())
