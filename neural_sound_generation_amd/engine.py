@@ -118,6 +118,8 @@ FUSED_1X1_BWD = _os.environ.get("NSG_FUSED_1X1_BWD", "1") == "1"    # the 1x1 co
 # high-resolution tensor), 0 = off.  Numbers: DESIGN.md section 6.
 # Measured in the step (same box, alternating): off 8.42 / 8.45 ms, decoder.3 only 8.26 / 8.35, all five 8.33 / 8.26 -- while the
 # conv kernel's in-region rate is 978 / 974, 974 / 960 and 927 / 935 TF: the one high-resolution pass is nearly all of the gain.
+# End of round 3 (scripts/ab_env.sh, six alternating pairs): all five 7.97-8.00 ms against 8.02-8.07 for decoder.3 only (0.6 %,
+# inside the box-to-box spread) at a 4 % lower rate of the dominant kernel; the default stays at 2.
 PATCH_BN_STATS = int(_os.environ.get("NSG_PATCH_BN_STATS", "2"))
 
 
