@@ -91,11 +91,12 @@ def test_vq_ragged_against_oracle(N, D, K):
     assert np.array_equal(codes.cpu().numpy(), e[want])
 
 
-def test_vq_full_size_properties():
-    """BASELINE size (16 clips of 80x1024 -> 81920 rows, K=512, D=128): size-independent checks --
-    run-to-run determinism, the gathered code is the indexed row, the reported minimum is attained
-    by the reported index, and a 4096-row sample is bit-exact against the oracle."""
-    N, D, K = 81920, 128, 512
+@pytest.mark.parametrize("N,D,K", [(81920, 128, 512), (655360, 128, 512), (163840, 256, 8192)])
+def test_vq_full_size_properties(N, D, K):
+    """BASELINE sizes (configs[1]: 16 clips and the bench's 128 clips of 80x1024 -> 81920 / 655360 rows, K=512, D=128; configs[3]:
+    32 clips, K=8192, D=256): size-independent checks -- run-to-run determinism, the gathered code is the indexed row, the
+    reported minimum is attained by the reported index, quantising the codes themselves is idempotent (exact search and bf16x3), and
+    a 4096-row sample is bit-exact against the oracle."""
     x, e = portable_rng.vq_case(N, D, K, 4242)
     xg, eg = gpu(torch.from_numpy(x)), gpu(torch.from_numpy(e))
     idx, codes, dmin = ops.vq_forward(xg, eg, want_dist=True)
@@ -103,10 +104,15 @@ def test_vq_full_size_properties():
     assert torch.equal(idx, idx2) and torch.equal(dmin, dmin2)
     assert torch.equal(codes, eg[idx])
     assert int(idx.min()) >= 0 and int(idx.max()) < K
-    sel = np.arange(0, N, 20)
+    sel = np.arange(0, N, N // 4096)
     want, wdist = O.vq_indices(x[sel], e, return_dist=True)
     assert np.array_equal(idx.cpu().numpy()[sel], want)
     assert np.array_equal(dmin.cpu().numpy()[sel], wdist)
+    # idempotence: a code vector quantises to a code at zero distance from it (itself, unless the codebook holds duplicates)
+    for impl in ("mfma", "bf16x3"):
+        again = ops.vq_forward(codes, eg, impl=impl)[0]
+        assert torch.equal(eg[again], codes), impl
+    del x, xg, codes
 
 
 @pytest.mark.parametrize("impl", ["mfma", "bf16x3"])
@@ -582,6 +588,41 @@ def test_patch_staged_conv_kernel(case):
         # one bf16 ulp at the value's own magnitude (2^-8 relative) plus the fp32 accumulation-order noise
         assert bool(((a - c).abs() <= c.abs() * 2.0 ** -7 + 1e-5 * scale).all()), f"{what}: differs from gemm_gather beyond a bf16 ulp"
         assert float((a != c).float().mean()) < 0.05, f"{what}: more than 5 % of the outputs round differently"
+
+
+@pytest.mark.parametrize("k,s,tr", [(3, 1, False), (4, 2, False), (4, 2, True)], ids=["3x3", "4x4s2", "4x4s2T"])
+def test_conv_full_size_batch_independence(k, s, tr):
+    """The bench's full size (128 clips; low-resolution grid 20 x 256, D = 128, bf16: 168 / 671 MB tensors, the 31-bit offsets'
+    range) through a size-independent property: a clip's output does not depend on what else is in the batch -- forward, the data
+    gradient with its fused add + mask and the BatchNorm statistics variant give, for the first, a middle and the last clip, the
+    bits a launch on that clip alone gives; the weight gradient of the batch is the sum of the clips' (fp32 sums, 1e-3 of scale)."""
+    B, C, bf = 128, 128, torch.bfloat16
+    IH, IW = (20, 256) if (s == 1 or tr) else (40, 512)
+    g = torch.Generator(device=DEV).manual_seed(k + s + int(tr))
+    d = ops.conv_desc(B, IH, IW, C, C, k, s, 1, transposed=tr, dtype=bf)
+    d1 = ops.conv_desc(1, IH, IW, C, C, k, s, 1, transposed=tr, dtype=bf)
+    wshape = (C, C, k, k)
+    w = torch.randn(*wshape, device=DEV, generator=g) * 0.05
+    b = torch.randn(C, device=DEV, generator=g) * 0.1
+    wf, wd = ops.pack_weights(d, w)
+    x = torch.randn(B, IH, IW, C, device=DEV, generator=g).to(bf)
+    dy = torch.randn(B, d.OH, d.OW, C, device=DEV, generator=g).to(bf)
+    skip = torch.randn(B, IH, IW, C, device=DEV, generator=g).to(bf)
+    rx = torch.relu(torch.randn(B, IH, IW, C, device=DEV, generator=g)).to(bf)
+    y = ops.conv_forward(d, x, wf, b)
+    ys, _, _ = ops.conv_forward_bnstats(d, x, wf, b)
+    dx = ops.conv_dgrad(d, dy, wd, add=skip, relu_x=rx)
+    assert torch.equal(y, ys)
+    dw, _ = ops.conv_wgrad(d, x, dy, wshape, want_bias=False)
+    for c in (0, 77, B - 1):
+        sl = slice(c, c + 1)
+        assert torch.equal(ops.conv_forward(d1, x[sl].contiguous(), wf, b), y[sl]), c
+        assert torch.equal(ops.conv_dgrad(d1, dy[sl].contiguous(), wd, add=skip[sl].contiguous(), relu_x=rx[sl].contiguous()), dx[sl]), c
+    acc = torch.zeros_like(dw, dtype=torch.float64)
+    for c in range(0, B, 16):        # 8 chunks of 16 clips
+        d16 = ops.conv_desc(16, IH, IW, C, C, k, s, 1, transposed=tr, dtype=bf)
+        acc += ops.conv_wgrad(d16, x[c:c + 16].contiguous(), dy[c:c + 16].contiguous(), wshape, want_bias=False)[0].double()
+    _close(dw.double().cpu(), acc.cpu(), tol=1e-3, what="weight gradient of the batch vs the sum over its chunks")
 
 
 def test_conv_rejects_unsupported_geometry():
