@@ -186,9 +186,16 @@ def resblock_forward(r, P: ResBlockParams, training: bool, out_dtype=None, relu_
 
 
 def resblock_bn2(saved):
-    """(h2, mean, invstd) of a ResBlock's closing BatchNorm from its saved forward state: for a producer of the block's incoming
-    gradient that forms that BatchNorm's backward sums itself (ops.vq_losses_indexed(bn=)); pass them on as bn2_sums=."""
-    return saved[3], saved[6], saved[7]
+    """(h2, mean, invstd) of a ResBlock's closing BatchNorm from its saved forward state, for a producer of the block's incoming
+    gradient that forms that BatchNorm's backward sums itself (ops.vq_losses_indexed(bn=)) and passes them on as bn2_sums= --
+    or None when the block's backward would not take them (it ran the separate operators: their BatchNorm backward is one call)."""
+    r, h1, a1, h2, m1, i1, m2, i2 = saved[:8]
+    return (h2, m2, i2) if a1 is None else None
+
+
+def encoder_closing_bn(saved):
+    """resblock_bn2 of the encoder's last ResBlock (the BatchNorm whose output is z_e), from encoder_forward's saved state."""
+    return resblock_bn2(saved[9])
 
 
 def resblock_backward(dy, saved, P: ResBlockParams, need_dx: bool = True, gout=None, bn2_sums=None):

@@ -148,8 +148,9 @@ class FusedTrainStep:
         bn2_sums = None
         if lean:
             # dz is the incoming gradient of the encoder's closing BatchNorm: its backward sums are formed while dz is written
-            h2, m2, i2 = engine.resblock_bn2(es[9])
-            if h2.dtype == self.dtype and engine.FUSED_1X1 and ops.bn_relu_conv1x1_supported(self.dtype, D):
+            bn2 = engine.encoder_closing_bn(es)
+            if bn2 is not None and bn2[0].dtype == self.dtype and ops.vq_losses_indexed_bn_supported(D):
+                h2, m2, i2 = bn2
                 loss_vq, dz, dg, db = ops.vq_losses_indexed(ze.view(-1, D), self.codebook.detach(), idx, dz_scale=self.beta, dz_add=dzq.view(-1, D),
                                                             grad_dtype=self.dtype, bn=(h2.view(-1, D), m2, i2), dgamma=self.g_enc[20],
                                                             dbeta=self.g_enc[21])
