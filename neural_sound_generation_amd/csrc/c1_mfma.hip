@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64) void c1_stats_from_moments_kernel(const double 
 // with G from BOTH halves of the split (x to ~2^-17: the weight gradient is now that exact, too).  Per element the ALU is left
 // with the ReLU decision (the forward's fma) and a select on the raw bf16 bits.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) void c1m_bwd_onepass_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void c1m_bwd_onepass_kernel(
     const float *__restrict__ img, const float *__restrict__ w, const float *__restrict__ bias, const bf16_t *__restrict__ dy,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ sums, float *__restrict__ partial, const C1Geom g)
