@@ -103,22 +103,27 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const PackJobs jobs)
 }
 
 // blocks of col2im_c1_kernel for a (B, LH, LW) record grid: one per tile, at most C1_LOSS_BLOCKS (they walk the tiles)
-constexpr int C1_COL2IM_TY = 7, C1_COL2IM_TX = 36;      // 252 positions per tile: the (20 + 1) x (256 + 1) and (40 + 1) x (512 + 1) grids of the model leave 2 - 5 % of a tile row / column empty
-inline int col2im_blocks(int B, int LH, int LW)
+constexpr int C1_COL2IM_TY = 4, C1_COL2IM_TX = 64;      // records per tile = threads per block; the model's grids (20 x 256, 40 x 512) tile exactly
+inline int col2im_blocks(int B, int HH, int WW)        // (HH, WW): the image; positions = 2 x 2 output blocks
 {
-    const int64_t nt = (int64_t)B * ((LH + 1 + C1_COL2IM_TY - 1) / C1_COL2IM_TY) * ((LW + 1 + C1_COL2IM_TX - 1) / C1_COL2IM_TX);
+    const int64_t nt = (int64_t)B * (((HH + 1) / 2 + C1_COL2IM_TY - 1) / C1_COL2IM_TY) * (((WW + 1) / 2 + C1_COL2IM_TX - 1) / C1_COL2IM_TX);
     return (int)(nt < C1_LOSS_BLOCKS ? (nt < 1 ? 1 : nt) : C1_LOSS_BLOCKS);
 }
 
-// dots [B][LH][LW][16] -> out [B][HH][WW]:  out[y][x] = bias + sum of the (<= 4) taps that reach it.
-// A thread owns the 2 x 2 outputs between four records: (2 ly + 1 .. 2 ly + 2) x (2 lx + 1 .. 2 lx + 2) take exactly one tap from each
-// of the records (ly, lx), (ly, lx + 1), (ly + 1, lx), (ly + 1, lx + 1), ly = -1 .. LH - 1, lx = -1 .. LW - 1.
-// A block walks tiles of C2I_TY x C2I_TX such positions; the (TY + 1) x (TX + 1) records a tile touches come in as whole 64-byte
-// records through LDS (16-byte pieces, consecutive threads on consecutive pieces; records outside the grid are zeros) -- read
-// straight from global memory every thread took 8 bytes out of eight different 64-byte records.  The next tile's records are
-// fetched into registers while this one is worked on (a tile is one global-memory latency otherwise).  Measured in the step at
-// 128 clips (252 MB): 73.7 us gathered -> 74.5 staged -> 62.6 with the prefetch; 1 536 blocks instead of 1 024: 73.
-// Taps are added in the order (ly+1,lx+1), (ly+1,lx), (ly,lx+1), (ly,lx).
+// dots [B][LH][LW][16] -> out [B][HH][WW]:  out[y][x] = bias + sum of the (<= 4) taps that reach it (y = 2 ly - 1 + kh, x = 2 lx - 1 + kw).
+// A thread owns the ALIGNED 2 x 2 outputs (2 ly .. 2 ly + 1) x (2 lx .. 2 lx + 1) of position (ly, lx), ly < ceil(HH / 2), lx <
+// ceil(WW / 2) (one past the record grid when the image extent is odd: its record is a zero): 8-byte loads of the
+// target and 8-byte stores, a wave = 512 contiguous bytes of an image row (owning the 2 x 2 between four records instead, every
+// access was a 4-byte one at a stride of 8).  Each of the four takes one tap from four of the 3 x 3 records around (ly, lx):
+//   (2ly,   2lx)   [1][1] of (ly, lx), [1][3] of (ly, lx-1), [3][1] of (ly-1, lx), [3][3] of (ly-1, lx-1)
+//   (2ly,   2lx+1) [1][2] of (ly, lx), [1][0] of (ly, lx+1), [3][2] of (ly-1, lx), [3][0] of (ly-1, lx+1)
+//   (2ly+1, 2lx)   [2][1] of (ly, lx), [2][3] of (ly, lx-1), [0][1] of (ly+1, lx), [0][3] of (ly+1, lx-1)
+//   (2ly+1, 2lx+1) [2][2] of (ly, lx), [2][0] of (ly, lx+1), [0][2] of (ly+1, lx), [0][0] of (ly+1, lx+1)
+// added from the record with the largest (row, column) down, as before.  A block walks tiles of C2I_TY x C2I_TX positions; the
+// (TY + 2) x (TX + 2) records a tile touches come in whole through LDS (16-byte pieces, consecutive threads on consecutive
+// pieces; records outside the grid are zeros), the next tile's while this one is worked on (a tile is one global-memory latency
+// otherwise).  Measured in the step at 128 clips (252 MB): 73.7 us gathered from global memory -> 62.6 staged + prefetched ->
+// 55-57 with the aligned 2 x 2 blocks.
 // LOSS: the reconstruction loss and its gradient in the same pass (train.py:118-129 on x_tilde = tanh(out)): per block a partial
 // of sum (pad(x_tilde) - target)^2 over the target's T >= WW columns, dpre = gscale (x_tilde - target)(1 - x_tilde^2) = the
 // gradient w.r.t. the tanh INPUT; x_tilde itself is stored only when out != null.
@@ -129,21 +134,23 @@ __device__ __forceinline__ float c1_tanh(float x)
     const float t = __expf(-2.f * fabsf(x));
     return copysignf(__fdividef(1.f - t, 1.f + t), x);
 }
-constexpr int C2I_TY = C1_COL2IM_TY, C2I_TX = C1_COL2IM_TX;      // positions per tile (<= 256 threads)
-static_assert(C2I_TY * C2I_TX <= 256, "one thread per position");
+constexpr int C2I_TY = C1_COL2IM_TY, C2I_TX = C1_COL2IM_TX;
+static_assert(C2I_TY * C2I_TX == 256, "one thread per position");
 template <bool LOSS>
 __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict__ dots, const float *__restrict__ bias, float *__restrict__ out,
                                                         int B, int LH, int LW, int HH, int WW, int tanh_out, const float *__restrict__ target,
                                                         int T, float gscale, float *__restrict__ dpre, double *__restrict__ partial)
 {
     typedef float f2 __attribute__((ext_vector_type(2)));
-    constexpr int RY = C2I_TY + 1, RX = C2I_TX + 1, RP = 16 + 4;      // records per tile; floats per record in LDS (80 bytes: b128 writes,
-    __shared__ __attribute__((aligned(16))) float rec[RY * RX * RP];  //  rows of records 20 banks apart)
-    const int tiles_y = (LH + 1 + C2I_TY - 1) / C2I_TY, tiles_x = (LW + 1 + C2I_TX - 1) / C2I_TX;
+    constexpr int RY = C2I_TY + 2, RX = C2I_TX + 2, RP = 16 + 4;      // records per tile; floats per record in LDS (80 bytes: b128 writes,
+    __shared__ __attribute__((aligned(16))) float rec[RY * RX * RP];  //  consecutive records 20 banks apart)
+    const int PY = (HH + 1) / 2, PX = (WW + 1) / 2;      // positions
+    const int tiles_y = (PY + C2I_TY - 1) / C2I_TY, tiles_x = (PX + C2I_TX - 1) / C2I_TX;
     const int64_t ntiles = (int64_t)B * tiles_y * tiles_x;
     const int tid = threadIdx.x;
     const int py = tid / C2I_TX, px = tid - py * C2I_TX;
     const float bv = bias ? bias[0] : 0.f;
+    const bool vec = (T & 1) == 0, vec_out = (WW & 1) == 0;      // 8-byte accesses need an even row pitch
     double lacc = 0.0, gacc = 0.0;      // loss partial; sum of dpre (= the transposed conv's bias gradient)
     constexpr int NPC = (RY * RX * 4 + 255) / 256;      // 16-byte pieces of a tile's records per thread
     v4f pc[NPC];
@@ -151,10 +158,10 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
         const int tx = (int)(tile % tiles_x);
         const int ty = (int)((tile / tiles_x) % tiles_y);
         b = (int)(tile / ((int64_t)tiles_x * tiles_y));
-        ly0 = ty * C2I_TY - 1;
-        lx0 = tx * C2I_TX - 1;
+        ly0 = ty * C2I_TY;
+        lx0 = tx * C2I_TX;
     };
-    auto fetch = [&](int64_t tile) {        // the tile's records -> registers (zeros outside the grid); in flight while the previous tile is worked on
+    auto fetch = [&](int64_t tile) {        // the tile's records and their halo -> registers (zeros outside the grid)
         int b, ly0, lx0;
         tile_coords(tile, b, ly0, lx0);
 #pragma unroll
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
             const int q = tid + 256 * i;
             const int r = min(q >> 2, RY * RX - 1), piece = q & 3;
             const int ry = r / RX, rx = r - ry * RX;
-            const int y = ly0 + ry, x = lx0 + rx;
+            const int y = ly0 - 1 + ry, x = lx0 - 1 + rx;
             const bool ok = y >= 0 && y < LH && x >= 0 && x < LW;
             const v4f v = *reinterpret_cast<const v4f *>(dots + (((size_t)b * LH + (ok ? y : 0)) * LW + (ok ? x : 0)) * 16 + 4 * piece);   // clamped, unconditional
             pc[i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
@@ -181,53 +188,45 @@ __global__ __launch_bounds__(256) void col2im_c1_kernel(const float *__restrict_
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         const int ly = ly0 + py, lx = lx0 + px;
-        if (py >= C2I_TY || ly >= LH || lx >= LW) continue;     // (idle threads, positions past the grid; every thread reaches the next round's barriers)
-        const float *r00 = rec + (py * RX + px) * RP, *r01 = r00 + RP, *r10 = r00 + RX * RP, *r11 = r10 + RP;
-        // record (ly, lx): taps [2][2..3], [3][2..3];  (ly, lx+1): [2][0..1], [3][0..1];  (ly+1, lx): [0][2..3], [1][2..3];  (ly+1, lx+1): [0][0..1], [1][0..1]
-        const f2 a2 = *reinterpret_cast<const f2 *>(r00 + 10), a3 = *reinterpret_cast<const f2 *>(r00 + 14);
-        const f2 b2 = *reinterpret_cast<const f2 *>(r01 + 8), b3 = *reinterpret_cast<const f2 *>(r01 + 12);
-        const f2 c0 = *reinterpret_cast<const f2 *>(r10 + 2), c1 = *reinterpret_cast<const f2 *>(r10 + 6);
-        const f2 d0 = *reinterpret_cast<const f2 *>(r11 + 0), d1 = *reinterpret_cast<const f2 *>(r11 + 4);
-        float tv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        if (LOSS) {         // the four target values, unconditional (clamped)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int yo = 2 * ly + 1 + j, xo = 2 * lx + 1 + k;
-                    const int yc = yo < 0 ? 0 : (yo >= HH ? HH - 1 : yo), xc = xo < 0 ? 0 : (xo >= WW ? WW - 1 : xo);
-                    tv[j][k] = target[((size_t)b * HH + yc) * T + xc];
-                }
-        }
-        float o[2][2];      // [row 2 ly + 1 + j][column 2 lx + 1 + k]   (records outside the grid are zeros: they add nothing)
-        o[0][0] = (((bv + d0.x) + c0.x) + b2.x) + a2.x;
-        o[0][1] = (((bv + d0.y) + c0.y) + b2.y) + a2.y;
-        o[1][0] = (((bv + d1.x) + c1.x) + b3.x) + a3.x;
-        o[1][1] = (((bv + d1.y) + c1.y) + b3.y) + a3.y;
-        float l4 = 0.f, g4 = 0.f;       // this position's (<= 4) terms in fp32, then one double add each
+        if (ly >= PY || lx >= PX) continue;     // (positions past the image; every thread reaches the next round's barriers)
+        // the 3 x 3 records around (ly, lx): row m, column n <-> record (ly - 1 + m, lx - 1 + n); tap [kh][kw] = float 4 kh + kw
+        const float *rc = rec + ((py + 1) * RX + (px + 1)) * RP;
+        auto tap = [&](int m, int n, int kh, int kw) { return rc[((m - 1) * RX + (n - 1)) * RP + 4 * kh + kw]; };
+        float o[2][2];      // [row 2 ly + j][column 2 lx + k]   (records outside the grid are zeros: they add nothing)
+        o[0][0] = (((bv + tap(1, 1, 1, 1)) + tap(1, 0, 1, 3)) + tap(0, 1, 3, 1)) + tap(0, 0, 3, 3);
+        o[0][1] = (((bv + tap(1, 2, 1, 0)) + tap(1, 1, 1, 2)) + tap(0, 2, 3, 0)) + tap(0, 1, 3, 2);
+        o[1][0] = (((bv + tap(2, 1, 0, 1)) + tap(2, 0, 0, 3)) + tap(1, 1, 2, 1)) + tap(1, 0, 2, 3);
+        o[1][1] = (((bv + tap(2, 2, 0, 0)) + tap(2, 1, 0, 2)) + tap(1, 2, 2, 0)) + tap(1, 1, 2, 2);
+        float l4 = 0.f, g4 = 0.f;       // this position's four terms in fp32, then one double add each
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int yo = 2 * ly + 1 + j;
-            if (yo < 0 || yo >= HH) continue;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int xo = 2 * lx + 1 + k;
-                if (xo < 0 || xo >= WW) continue;
-                const float v = tanh_out ? c1_tanh(o[j][k]) : o[j][k];
-                if (out) out[((size_t)b * HH + yo) * WW + xo] = v;
-                if (LOSS) {
-                    const float dlt = v - tv[j][k];
-                    l4 = __builtin_fmaf(dlt, dlt, l4);
-                    const float gp = gscale * dlt * (1.f - v * v);
-                    dpre[((size_t)b * HH + yo) * WW + xo] = gp;
-                    g4 += gp;
-                }
+            const int yo = 2 * ly + j, xo = 2 * lx;
+            if (yo >= HH) continue;
+            const bool two = xo + 1 < WW;       // (an odd image width: the last position holds one column)
+            const size_t io = ((size_t)b * HH + yo) * WW + xo;
+            const float v0 = tanh_out ? c1_tanh(o[j][0]) : o[j][0], v1 = tanh_out ? c1_tanh(o[j][1]) : o[j][1];
+            if (out) {
+                if (vec_out) *reinterpret_cast<f2 *>(out + io) = f2{v0, v1};
+                else { out[io] = v0; if (two) out[io + 1] = v1; }
             }
-            if (LOSS && lx == LW - 1)          // the target's columns past the image: (0 - c)^2, no gradient
-                for (int xo = WW; xo < T; ++xo) {
-                    const float cv = target[((size_t)b * HH + yo) * T + xo];
-                    lacc += (double)(cv * cv);
-                }
+            if (LOSS) {
+                const float *tp = target + ((size_t)b * HH + yo) * T + xo;
+                f2 tv;
+                if (vec) tv = *reinterpret_cast<const f2 *>(tp);        // (T >= WW, both even: inside the row)
+                else { tv.x = tp[0]; tv.y = two ? tp[1] : 0.f; }
+                const float d0 = v0 - tv.x, d1 = two ? v1 - tv.y : 0.f;
+                l4 = __builtin_fmaf(d1, d1, __builtin_fmaf(d0, d0, l4));
+                const float gp0 = gscale * d0 * (1.f - v0 * v0), gp1 = two ? gscale * d1 * (1.f - v1 * v1) : 0.f;
+                if (vec_out) *reinterpret_cast<f2 *>(dpre + io) = f2{gp0, gp1};
+                else { dpre[io] = gp0; if (two) dpre[io + 1] = gp1; }
+                g4 += gp0;
+                g4 += gp1;
+                if (lx == PX - 1)              // the target's columns past the image: (0 - c)^2, no gradient
+                    for (int xx = WW; xx < T; ++xx) {
+                        const float cv = target[((size_t)b * HH + yo) * T + xx];
+                        lacc += (double)(cv * cv);
+                    }
+            }
         }
         lacc += (double)l4;
         gacc += (double)g4;
@@ -602,7 +601,7 @@ static int conv_forward_impl(const nsg_conv_desc *d, const void *x, const void *
     float *dots = reinterpret_cast<float *>(workspace);
     int rc = nsg_launch_gather_gemm(gg_1x1(x, w_fwd, nullptr, dots, Mp, d->C_in, 16, flags & NSG_RELU_IN, d->dtype, NSG_F32), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(col2im_blocks(d->B, d->IH, d->IW)), dim3(256), 0, s, dots, bias,
+    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(col2im_blocks(d->B, d->OH, d->OW)), dim3(256), 0, s, dots, bias,
                        reinterpret_cast<float *>(y), d->B, d->IH, d->IW, d->OH, d->OW, (flags & NSG_TANH_OUT) ? 1 : 0, (const float *)nullptr, 0,
                        0.f, (float *)nullptr, (double *)nullptr);
     return nsg_check_launch("col2im_c1_kernel");
@@ -688,7 +687,7 @@ int nsg_conv_dgrad_relu_add(const nsg_conv_desc *d, const void *dy, const void *
     float *dots = reinterpret_cast<float *>(workspace);
     int rc = nsg_launch_gather_gemm(gg_1x1(dy, w_dgrad, nullptr, dots, Mp, d->C_out, 16, 0, d->dtype, NSG_F32), s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(col2im_blocks(d->B, d->OH, d->OW)), dim3(256), 0, s, dots,
+    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(col2im_blocks(d->B, d->IH, d->IW)), dim3(256), 0, s, dots,
                        (const float *)nullptr, reinterpret_cast<float *>(dx), d->B, d->OH, d->OW, d->IH, d->IW, 0, (const float *)nullptr, 0, 0.f,
                        (float *)nullptr, (double *)nullptr);
     return nsg_check_launch("col2im_c1_kernel");
@@ -771,7 +770,7 @@ int nsg_bn_relu_c1convt_forward(const void *u, int32_t dtype, const float *mean,
     float *dots = reinterpret_cast<float *>(workspace);
     int rc = nsg_launch_bnrelu_dots(u, mean, invstd, gamma, beta, w, dots, (int64_t)B * H * W, C, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(col2im_blocks(B, H, W)), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H,
+    hipLaunchKernelGGL(col2im_c1_kernel<false>, dim3(col2im_blocks(B, 2 * H, 2 * W)), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H,
                        2 * W, (flags & NSG_TANH_OUT) ? 1 : 0, (const float *)nullptr, 0, 0.f, (float *)nullptr, (double *)nullptr);
     return nsg_check_launch("col2im_c1_kernel");
 }
@@ -800,7 +799,7 @@ int nsg_bn_relu_c1convt_forward_mse(const void *u, int32_t dtype, const float *m
     int rc = nsg_launch_bnrelu_dots(u, mean, invstd, gamma, beta, w, dots, (int64_t)B * H * W, C, s);
     if (rc) return rc;
     const int64_t n = (int64_t)B * 2 * H * T;
-    const int nb = col2im_blocks(B, H, W);
+    const int nb = col2im_blocks(B, 2 * H, 2 * W);
     hipLaunchKernelGGL(col2im_c1_kernel<true>, dim3(nb), dim3(256), 0, s, dots, bias, y, B, H, W, 2 * H, 2 * W, 1, target, T,
                        grad_scale * 2.0f / (float)n, dpre, partial);
     rc = nsg_check_launch("col2im_c1_kernel<loss>");
