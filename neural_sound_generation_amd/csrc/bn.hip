@@ -328,13 +328,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T *__restrict
 // dbeta[c] = sum_s partial[s][c], dgamma[c] = sum_s partial[s][C + c]: one block per 4 channels, tree sums in double
 // colsum_partial != null: out3[c] = sum_s colsum_partial[s][c] in the same launch (slab_sum_final_kernel's job: a producer that
 // leaves both kinds of partials, the fused 1x1 backward, pays one finaliser launch instead of two)
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta,
-                                                           const float *__restrict__ colsum_partial, float *out3)
+__device__ __forceinline__ void bn_bwd_final_body(int bid, const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta,
+                                                  const float *__restrict__ colsum_partial, float *out3)
 {
     constexpr int PER = MAX_SLABS / 256;
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * 4;
+    const int c0 = bid * 4;
     v4f a[PER], b[PER], c3[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -363,6 +363,47 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restri
             if (colsum_partial) out3[c0 + e] = (float)s3;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta,
+                                                           const float *__restrict__ colsum_partial, float *out3)
+{
+    bn_bwd_final_body(blockIdx.x, partial, nslab, C, dgamma, dbeta, colsum_partial, out3);
+}
+
+// bn_bwd_final_kernel in blocks 0 .. C / 4 - 1 and, in the blocks behind them, wdst[e] = sum over slabs (slab order) of
+// wpartial[slab][e], e < wn -- wgrad_reduce_kernel for one tap, its sharing of the slabs among 8 lanes and its order of adds: the
+// two finalisers of the fused 1x1 backward (BatchNorm sums in front, the weight gradient's block partials) in ONE launch (a
+// dependent launch costs 4.7 us here whatever it does).
+__global__ __launch_bounds__(256) void bn_bwd_final_wreduce_kernel(const float *__restrict__ partial, int nslab, int C, float *dgamma, float *dbeta,
+                                                                   const float *__restrict__ colsum_partial, float *out3,
+                                                                   const float *__restrict__ wpartial, float *__restrict__ wdst, int wn, int wsplit)
+{
+    const int nbn = C / 4;
+    if ((int)blockIdx.x < nbn) {
+        bn_bwd_final_body(blockIdx.x, partial, nslab, C, dgamma, dbeta, colsum_partial, out3);
+        return;
+    }
+    __shared__ float wred[256];
+    const int per_block = 256 / wsplit;
+    const int tid = threadIdx.x;
+    const int sub = tid / per_block, loc = tid - sub * per_block;
+    const int e = ((int)blockIdx.x - nbn) * per_block + loc;
+    float sacc = 0.f;
+    if (e < wn) {
+        const int chunk = (nslab + wsplit - 1) / wsplit;
+        const int s0 = sub * chunk, s1 = min(nslab, s0 + chunk);
+        if (s1 > s0) sacc = nsg_strided_sum<float>(wpartial + (size_t)s0 * wn + e, (size_t)wn, s1 - s0);
+    }
+    if (wsplit > 1) {
+        wred[tid] = sacc;
+        __syncthreads();
+        if (sub == 0) {
+            sacc = 0.f;
+            for (int k = 0; k < wsplit; ++k) sacc += wred[k * per_block + loc];
+        }
+    }
+    if (sub == 0 && e < wn) wdst[e] = sacc;
 }
 
 // dx = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), slab-structured; optionally also the per-slab
@@ -571,6 +612,18 @@ int nsg_launch_bn_bwd_final_colsum(const float *partial, const float *colsum_par
     if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "bn_bwd_final: %d slabs / %d channels not supported", nslab, C);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 4), dim3(256), 0, s, partial, nslab, C, dgamma, dbeta, colsum_partial, colsum);
     return nsg_check_launch("bn_bwd_final_kernel");
+}
+
+// ... and the slab sum of the weight gradient's block partials wpartial [nslab][wn] -> wdst [wn] (one tap: nsg_launch_wgrad_reduce's result, bit for bit)
+int nsg_launch_bn_bwd_final_wreduce(const float *partial, const float *colsum_partial, int nslab, int C, float *dgamma, float *dbeta, float *colsum,
+                                    const float *wpartial, float *wdst, int wn, hipStream_t s)
+{
+    if (nslab < 1 || nslab > MAX_SLABS || C % 4) return nsg_fail(NSG_E_INVALID, "bn_bwd_final: %d slabs / %d channels not supported", nslab, C);
+    const int split = (nslab >= 64 && wn < 512 * 256) ? 8 : 1;      // (nsg_launch_wgrad_reduce's choice)
+    const int wblocks = (wn + 256 / split - 1) / (256 / split);
+    hipLaunchKernelGGL(bn_bwd_final_wreduce_kernel, dim3(C / 4 + wblocks), dim3(256), 0, s, partial, nslab, C, dgamma, dbeta, colsum_partial, colsum,
+                       wpartial, wdst, wn, split);
+    return nsg_check_launch("bn_bwd_final_wreduce_kernel");
 }
 
 int nsg_launch_slab_sum_final(const float *partial, int nslab, int C, float *out, hipStream_t s)

@@ -30,7 +30,7 @@ size_t nsg_flat1x1_fused_bwd_workspace_bytes(int C);
 int nsg_launch_flat1x1_fused_bwd(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
                                  const float *dbeta, const float *w, void *dx, float *dw, int64_t M, int C, void *ws, int *nblocks,
                                  const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
-                                 const float *prev_beta, float **colsum_partial, float **prev_partial, hipStream_t s);
+                                 const float *prev_beta, float **colsum_partial, float **prev_partial, float **dw_partial, hipStream_t s);
 // c1_mfma.hip / stencil_c1.hip: pieces of the fused output layer (nsg_bn_relu_c1convt_*)
 bool nsg_c1m_supported(int C);
 int nsg_launch_bnrelu_dots(const void *u, const float *mean, const float *invstd, const float *gamma, const float *beta, const float *w,
@@ -965,12 +965,13 @@ int nsg_bn_backward_conv1x1_dgrad_wgrad(const void *h, const void *dy, const flo
                 "nsg_bn_backward_conv1x1_dgrad_wgrad: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int nblocks = 0;
-    float *colsum_partial = nullptr, *prev_partial = nullptr;
+    float *colsum_partial = nullptr, *prev_partial = nullptr, *dw_partial = nullptr;
     int rc = nsg_launch_flat1x1_fused_bwd(h, dy, mean, invstd, gamma, dgamma, dbeta, w, dx, dw, M, C, workspace, &nblocks, prev_x, prev_mean,
-                                          prev_invstd, prev_gamma, prev_beta, &colsum_partial, &prev_partial, s);
+                                          prev_invstd, prev_gamma, prev_beta, &colsum_partial, &prev_partial, &dw_partial, s);
     if (rc) return rc;
-    if (dh_colsum) return nsg_launch_bn_bwd_final_colsum(prev_partial, colsum_partial, nblocks, C, prev_dgamma, prev_dbeta, dh_colsum, s);
-    return nsg_launch_bn_bwd_final(prev_partial, nblocks, C, prev_dgamma, prev_dbeta, s);
+    // one finaliser launch: the sums of the BatchNorm in front, the column sums of dh, the block partials of dw
+    return nsg_launch_bn_bwd_final_wreduce(prev_partial, dh_colsum ? colsum_partial : nullptr, nblocks, C, prev_dgamma, prev_dbeta, dh_colsum,
+                                           dw_partial, dw, C * C, s);
 }
 
 }  // extern "C"

@@ -915,7 +915,7 @@ int nsg_launch_flat1x1_forward(const void *x, const float *mean, const float *in
 }
 
 // The backward of the 1x1 conv in one pass (C = 128): dx, the column sums of dh, the sums of the BatchNorm in front, and dw
-// (partials per block in the workspace, reduced here).  dh itself is not stored.
+// (partials per block in the workspace: *dw_partial [blocks][C][C], summed by the caller).  dh itself is not stored.
 constexpr int FLAT_FUSED_BLOCKS = 256;
 bool nsg_flat1x1_fused_bwd_supported(int dtype, int C) { return dtype == NSG_BF16 && C == 128; }
 size_t nsg_flat1x1_fused_bwd_workspace_bytes(int C)
@@ -926,8 +926,9 @@ size_t nsg_flat1x1_fused_bwd_workspace_bytes(int C)
 int nsg_launch_flat1x1_fused_bwd(const void *h, const void *dy, const float *mean, const float *invstd, const float *gamma, const float *dgamma,
                                  const float *dbeta, const float *w, void *dx, float *dw, int64_t M, int C, void *ws, int *nblocks,
                                  const void *prev_x, const float *prev_mean, const float *prev_invstd, const float *prev_gamma,
-                                 const float *prev_beta, float **colsum_partial, float **prev_partial, hipStream_t s)
+                                 const float *prev_beta, float **colsum_partial, float **prev_partial, float **dw_partial, hipStream_t s)
 {
+    (void)dw;       // (the caller sums the block partials of dw together with the BatchNorm sums: nsg_launch_bn_bwd_final_wreduce)
     char *wsb = reinterpret_cast<char *>(ws);
     FlatParams p = {};
     p.x = reinterpret_cast<const bf16_t *>(h); p.g = reinterpret_cast<const bf16_t *>(dy); p.w = w;
@@ -949,9 +950,8 @@ int nsg_launch_flat1x1_fused_bwd(const void *h, const void *dy, const float *mea
     int rc = nsg_lds_opt_in(once, {reinterpret_cast<const void *>(&flat_bwd_fused_kernel)}, lds, "flat_gemm (fused backward)");
     if (rc != NSG_OK) return rc;
     hipLaunchKernelGGL(flat_bwd_fused_kernel, dim3(blocks), dim3(512), lds, s, p, dwp);
-    rc = nsg_check_launch("flat_bwd_fused_kernel");
-    if (rc != NSG_OK) return rc;
-    return nsg_launch_wgrad_reduce(dwp, dw, blocks, 1, C, C, s);
+    *dw_partial = dwp;
+    return nsg_check_launch("flat_bwd_fused_kernel");
 }
 
 // dh = BatchNorm backward of dy at input h (no ReLU), stored; dx = dh * W; partial column sums of dh -> colsum_partial [blocks][C];

@@ -263,6 +263,8 @@ int nsg_bn_stats_from_tiles(const float *tiles, int ntiles, int64_t M, int C, fl
 void nsg_bn_slab_geom(int64_t M, int *nslab, int *rows);      // bn.hip: slabs of nsg_bn_backward_sums over M rows
 int nsg_launch_bn_bwd_final(const float *partial, int nslab, int C, float *dgamma, float *dbeta, hipStream_t s);
 // ... and colsum[c] = sum_s colsum_partial[s][c] in the same launch
+int nsg_launch_bn_bwd_final_wreduce(const float *partial, const float *colsum_partial, int nslab, int C, float *dgamma, float *dbeta, float *colsum,
+                                    const float *wpartial, float *wdst, int wn, hipStream_t s);
 int nsg_launch_bn_bwd_final_colsum(const float *partial, const float *colsum_partial, int nslab, int C, float *dgamma, float *dbeta,
                                    float *colsum, hipStream_t s);
 // out[c] = sum_s partial[s][c] over nslab <= 1024 slabs of [C] (fixed order, double)
